@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- Mray-steps/s and frames/s of the hot path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched
+under ``python -m torch.distributed.run --nproc-per-node N`` (one rank per GPU).  Rank 0 prints
+ONE JSON line.
+
+* step      one frame of the hot path: fused ray march + bloom H/V + final combine
+            (TaichiRenderer.render(), render.py:3865-3923) with the scene resident in HBM;
+* workload  BASELINE.json configs[1]: fhd 1920x1080, default scene (pov 6 0 0.5, fov 90,
+            step_size 0.1, disk 2-15, tilt 0, AA off), procedural disk texture + skybox;
+* N > 1     the path shards by independent frames (configs[4], frames f % N == rank): every
+            rank renders its own fhd frames, no data-path collective => "scaling": "weak";
+* value     total ray-steps of all ranks / max-over-ranks wall time of the K timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# SURVEY.md 8(d) / BASELINE.md 2: algorithmic cost of the dominant kernel (the march, AA off)
+MARCH_BYTES_PER_PIXEL = 110.0     # 24 B framebuffer stores + 0.67*64 B disk texels + 0.90*48 B sky texels
+MARCH_FLOP_PER_RAY_STEP = 205.0   # 190 flop + 7 sqrt + 8 div, each counted once
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
+
+WORKLOADS = {
+    "fhd": dict(width=1920, height=1080, cam_pos=[6.0, 0.0, 0.5], fov=90.0, step_size=0.1, anti_alias="disabled",
+                disk_tilt=0.0),
+    "sd": dict(width=640, height=360, cam_pos=[6.0, 0.0, 0.5], fov=90.0, step_size=0.1, anti_alias="disabled",
+               disk_tilt=0.0),
+    "4k": dict(width=3840, height=2160, cam_pos=[6.0, 0.0, 0.5], fov=90.0, step_size=0.1, anti_alias="lod_radius",
+               disk_tilt=25.0),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="fhd", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-kernel", action="store_true", help="A/B: tile schedule instead of persistent refill")
+    return ap.parse_args()
+
+
+def cpu_baseline(wl, sky, tex):
+    """Oracle (kind 'port': the reference's Taichi CPU path cannot run here -- taichi is not
+    installed) on the host cores, -O3 -ffast-math + OpenMP, one full frame of the same workload."""
+    from oracle import oracle as O
+    lib = O.load(fast=True)
+    cores = int(lib.oracle_num_threads())
+    ora = O.OracleRenderer(wl["width"], wl["height"], sky, tex, step_size=wl["step_size"], r_max=10.0,
+                           r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=wl["disk_tilt"],
+                           anti_alias=wl["anti_alias"], fast=True)
+    # the reference integrates the differentials even with AA off (render.py:3866, 4073): time what it does
+    t0 = time.perf_counter()
+    img, disk = ora.march(wl["cam_pos"], wl["fov"], skip_differentials=False, want_steps=False)
+    t_march = time.perf_counter() - t0
+    steps = ora.last_total_steps
+    t0 = time.perf_counter()
+    ora.bloom(disk)
+    t_bloom = time.perf_counter() - t0
+    t_frame = t_march + t_bloom
+    # the same march with the differentials skipped (what the HIP path executes for AA off)
+    t0 = time.perf_counter()
+    ora.march(wl["cam_pos"], wl["fov"], skip_differentials=True, want_steps=False)
+    t_skip = time.perf_counter() - t0
+    return {"value": steps / t_frame / 1e6, "unit": "Mray-steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 full {wl['width']}x{wl['height']} frame (march with differentials as the reference "
+                      f"executes it + bloom), {steps} ray-steps in {t_frame:.2f}s",
+            "fps": 1.0 / t_frame,
+            "march_only_skip_diff_mray_steps_per_s": steps / t_skip / 1e6}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from bhr_amd import workloads
+    wl = WORKLOADS[args.workload]
+    renderer, sky, tex, scene_note = workloads.make_scene(wl, device_index=local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        renderer.sync()
+
+    # frames sharded round-robin over ranks (configs[4]); the camera is the static default pov
+    compaction = not args.tile_kernel
+    for _ in range(args.warmup):
+        renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction)
+    renderer.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    c = renderer.counters()
+    steps_per_frame = c["ray_steps"]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([float(steps_per_frame)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        total_steps = float(s.item()) * args.steps
+    else:
+        total_steps = float(steps_per_frame) * args.steps
+
+    if rank == 0:
+        n_frames = c["frames_timed"]
+        march_ms = c["march_ms_sum"] / max(n_frames, 1)
+        bloom_ms = c["bloom_ms_sum"] / max(n_frames, 1)
+        pixels = wl["width"] * wl["height"]
+        alg_bytes = MARCH_BYTES_PER_PIXEL * pixels
+        achieved_gbs = alg_bytes / (march_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "march_traffic.json")
+        if os.path.isfile(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                traffic = None
+        valu_tflops = MARCH_FLOP_PER_RAY_STEP * (c["ray_steps_sum"] / max(n_frames, 1)) / (march_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mray-steps/s", "value": total_steps / elapsed / 1e6, "unit": "Mray-steps/s",
+            "fps": world * args.steps / elapsed,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} {wl['width']}x{wl['height']} default scene, pov 6 0 0.5, "
+                                   f"fov {wl['fov']:g}, step_size {wl['step_size']}, anti_alias {wl['anti_alias']}",
+                       "scene": scene_note, "frames_per_rank": args.steps,
+                       "sharding": "independent frames per rank, no collective",
+                       "march_schedule": "tile" if args.tile_kernel else "persistent+refill",
+                       "ray_steps_per_frame": int(steps_per_frame), "steps_per_ray": steps_per_frame / pixels},
+            "kernel_ms": {"march": march_ms, "bloom_and_combine": bloom_ms, "frames_timed": n_frames,
+                          "march_vgprs": c["march_vgprs"]},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "march", "algorithmic_bytes_per_launch": alg_bytes},
+            # the march is not HBM bound: the governing ceiling is non-matrix FP32
+            "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_FP32_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": valu_tflops / VALU_FP32_PEAK_TFLOPS,
+                              "flop_per_ray_step": MARCH_FLOP_PER_RAY_STEP},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl, sky, tex)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    renderer.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""ctypes binding of include/bhr.h.
+
+There is deliberately no fallback: if libbhr_hip.so is missing or cannot be
+loaded this module raises, and every renderer entry point goes through it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import library_path
+
+BHR_OK = 0
+BHR_ERR_INVALID, BHR_ERR_NO_DEVICE, BHR_ERR_HIP, BHR_ERR_STATE, BHR_ERR_NOMEM = -1, -2, -3, -4, -5
+
+SKIP_DIFFERENTIALS, SKIP_BLOOM, NO_COMPACTION = 1, 2, 4
+LAYER_FINAL, LAYER_BG, LAYER_DISK, LAYER_BLUR = 0, 1, 2, 3
+
+# every symbol include/bhr.h declares (tests check the .so exports exactly these)
+SYMBOLS = (
+    "bhr_last_error", "bhr_abi_version", "bhr_device_count", "bhr_create", "bhr_destroy", "bhr_sync",
+    "bhr_set_skybox", "bhr_set_disk_texture", "bhr_get_disk_texture", "bhr_get_disk_mip", "bhr_num_mip_levels",
+    "bhr_bg_init", "bhr_generate_background", "bhr_set_entity_staging", "bhr_set_comp", "bhr_read_comp",
+    "bhr_fill_comp_slice", "bhr_set_compose_stats", "bhr_compose_texture", "bhr_eval_noise", "bhr_render",
+    "bhr_read_layer", "bhr_read_final_u8", "bhr_get_counters", "bhr_timing_reset", "bhr_group_render",
+)
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("row0", C.c_int32), ("row1", C.c_int32),
+                ("step_size", C.c_float), ("r_max", C.c_float), ("r_disk_inner", C.c_float),
+                ("r_disk_outer", C.c_float), ("disk_tilt_deg", C.c_float), ("anti_alias", C.c_int32),
+                ("aa_strength", C.c_float), ("disk_rotation_speed", C.c_float), ("device", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3),
+                ("forward", C.c_float * 3), ("pixel_width", C.c_float), ("pixel_height", C.c_float),
+                ("r_escape", C.c_float), ("t_offset", C.c_float)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("ray_steps", C.c_uint64), ("rays", C.c_uint64), ("march_ms", C.c_float), ("bloom_ms", C.c_float),
+                ("frame_ms", C.c_float), ("background_ms", C.c_float), ("compose_ms", C.c_float),
+                ("march_vgprs", C.c_int32), ("march_lds_bytes", C.c_int32), ("frames_timed", C.c_int32),
+                ("march_ms_sum", C.c_float), ("bloom_ms_sum", C.c_float), ("ray_steps_sum", C.c_uint64)]
+
+
+class BhrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libbhr_hip: {msg} (status {code})")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libbhr_hip.so and declare every prototype.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.isfile(path):
+        raise ImportError(
+            f"{path} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    F, I32, P = C.POINTER(C.c_float), C.c_int32, C.c_void_p
+    lib.bhr_last_error.restype = C.c_char_p
+    lib.bhr_abi_version.restype = I32
+    lib.bhr_device_count.restype = I32
+    lib.bhr_create.argtypes = [C.POINTER(Config), C.POINTER(P)]
+    lib.bhr_destroy.argtypes = [P]
+    lib.bhr_destroy.restype = None
+    lib.bhr_sync.argtypes = [P]
+    lib.bhr_set_skybox.argtypes = [P, F, I32, I32]
+    lib.bhr_set_disk_texture.argtypes = [P, F, I32, I32]
+    lib.bhr_get_disk_texture.argtypes = [P, F]
+    lib.bhr_get_disk_mip.argtypes = [P, I32, F]
+    lib.bhr_num_mip_levels.argtypes = [P]
+    lib.bhr_bg_init.argtypes = [P, I32, I32, I32, C.c_float, F, F]
+    lib.bhr_generate_background.argtypes = [P, C.c_float]
+    lib.bhr_set_entity_staging.argtypes = [P, F]
+    lib.bhr_set_comp.argtypes = [P, F]
+    lib.bhr_read_comp.argtypes = [P, F]
+    lib.bhr_fill_comp_slice.argtypes = [P, I32, C.c_float]
+    lib.bhr_set_compose_stats.argtypes = [P, C.c_float, C.c_float, F]
+    lib.bhr_compose_texture.argtypes = [P, C.c_float, I32, C.c_float]
+    lib.bhr_eval_noise.argtypes = [P, F, C.c_int64, I32, I32, C.c_float, C.c_float, F]
+    lib.bhr_render.argtypes = [P, C.POINTER(Camera), C.c_uint32]
+    lib.bhr_read_layer.argtypes = [P, I32, F]
+    lib.bhr_read_final_u8.argtypes = [P, C.POINTER(C.c_uint8)]
+    lib.bhr_get_counters.argtypes = [P, C.POINTER(Counters)]
+    lib.bhr_timing_reset.argtypes = [P]
+    lib.bhr_group_render.argtypes = [C.POINTER(P), I32, C.POINTER(Camera), C.c_uint32, F]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("bhr_last_error", "bhr_destroy"):
+            fn.restype = I32
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Map a bhr_status to the exception the reference raises in the same situation."""
+    if rc == BHR_OK:
+        return
+    msg = load().bhr_last_error().decode("utf-8", "replace")
+    if rc == BHR_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == BHR_ERR_STATE:
+        raise AssertionError(msg)  # the reference asserts on call-order violations (render.py:3558, 3802)
+    raise BhrError(rc, msg)
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))

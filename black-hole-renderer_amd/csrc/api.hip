@@ -1,0 +1,546 @@
+// api.hip -- the extern "C" surface declared in include/bhr.h.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "bhr_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+template <typename T>
+int32_t dev_alloc(T **p, size_t count) {
+    *p = nullptr;
+    if (count == 0) return BHR_OK;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return bhr_fail(BHR_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    }
+    return BHR_OK;
+}
+
+#define BHR_TRY(expr)            \
+    do {                         \
+        int32_t rc__ = (expr);   \
+        if (rc__ != BHR_OK) return rc__; \
+    } while (0)
+
+int32_t use_device(bhr_ctx *ctx) {
+    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    return BHR_OK;
+}
+
+int32_t ensure_pinned(bhr_ctx *ctx, size_t bytes) {
+    if (ctx->h_pinned_bytes >= bytes) return BHR_OK;
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    ctx->h_pinned = nullptr;
+    ctx->h_pinned_bytes = 0;
+    BHR_HIP(hipHostMalloc((void **)&ctx->h_pinned, bytes, hipHostMallocDefault));
+    ctx->h_pinned_bytes = bytes;
+    return BHR_OK;
+}
+
+// device -> caller memory through the pinned staging buffer (synchronises the stream)
+int32_t download(bhr_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
+    BHR_TRY(ensure_pinned(ctx, bytes));
+    BHR_HIP(hipMemcpyAsync(ctx->h_pinned, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BHR_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(dst, ctx->h_pinned, bytes);
+    return BHR_OK;
+}
+
+int32_t upload(bhr_ctx *ctx, void *d_dst, const void *src, size_t bytes) {
+    // pageable source: hipMemcpyAsync stages internally and is ordered on the stream
+    BHR_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BHR_HIP(hipStreamSynchronize(ctx->stream));
+    return BHR_OK;
+}
+
+__global__ void quantize_u8_kernel(const float *__restrict__ src, uint8_t *__restrict__ dst, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    // save_image: (np.clip(x, 0, 1) * 255).astype(np.uint8) -- truncation (render.py:423)
+    for (; i < n; i += stride) dst[i] = (uint8_t)(int)(fminf(fmaxf(src[i], 0.0f), 1.0f) * 255.0f);
+}
+
+void free_scene(bhr_ctx *ctx) {
+    if (ctx->d_mips) (void)hipFree(ctx->d_mips);
+    ctx->d_mips = nullptr;
+}
+
+void free_bg(bhr_ctx *ctx) {
+    if (ctx->d_comp) (void)hipFree(ctx->d_comp);
+    if (ctx->d_edge) (void)hipFree(ctx->d_edge);
+    if (ctx->d_omega) (void)hipFree(ctx->d_omega);
+    if (ctx->d_row_stats) (void)hipFree(ctx->d_row_stats);
+    ctx->d_comp = ctx->d_edge = ctx->d_omega = ctx->d_row_stats = nullptr;
+    ctx->bg_ready = 0;
+}
+
+// Allocates the packed mip stack for an (n_r, n_phi) texture.
+int32_t alloc_mips(bhr_ctx *ctx, int32_t n_r, int32_t n_phi) {
+    int64_t off = 0;
+    int32_t h = n_r, w = n_phi;
+    for (int l = 0; l < BHR_NUM_MIP_LEVELS; ++l) {
+        ctx->mip_off[l] = (int32_t)off;
+        ctx->mip_h[l] = h;
+        ctx->mip_w[l] = w;
+        off += (int64_t)h * w;
+        // generate_disk_mipmaps stops when h < 2 or w < 2 (render.py:1118-1119)
+        if (h < 2 || w < 2) { h = 0; w = 0; } else { h /= 2; w /= 2; }
+    }
+    if (off >= (1ll << 31)) return bhr_fail(BHR_ERR_INVALID, "disk texture too large (%d x %d)", n_r, n_phi);
+    ctx->mip_texels = off;
+    ctx->n_r = n_r;
+    ctx->n_phi = n_phi;
+    BHR_TRY(dev_alloc(&ctx->d_mips, (size_t)off));
+    BHR_HIP(hipMemsetAsync(ctx->d_mips, 0, (size_t)off * sizeof(float4), ctx->stream));
+    return BHR_OK;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+}  // namespace
+
+int32_t bhr_fail(int32_t code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+const char *bhr_last_error(void) { return g_err; }
+int32_t bhr_abi_version(void) { return BHR_ABI_VERSION; }
+
+int32_t bhr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
+    if (!cfg || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_create: null argument");
+    *out = nullptr;
+    if (cfg->width <= 0 || cfg->height <= 0) return bhr_fail(BHR_ERR_INVALID, "bhr_create: bad image size %dx%d", cfg->width, cfg->height);
+    if (cfg->row0 < 0 || cfg->row1 > cfg->height || cfg->row0 >= cfg->row1)
+        return bhr_fail(BHR_ERR_INVALID, "bhr_create: bad row block [%d,%d) for height %d", cfg->row0, cfg->row1, cfg->height);
+    if (!(cfg->step_size > 0.0f)) return bhr_fail(BHR_ERR_INVALID, "bhr_create: step_size must be positive");
+    if (!(cfg->r_disk_inner < cfg->r_disk_outer)) return bhr_fail(BHR_ERR_INVALID, "bhr_create: r_disk_inner must be < r_disk_outer");
+    int ndev = bhr_device_count();
+    if (ndev <= 0) return bhr_fail(BHR_ERR_NO_DEVICE, "bhr_create: no HIP device visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return bhr_fail(BHR_ERR_NO_DEVICE, "bhr_create: device %d out of range (have %d)", cfg->device, ndev);
+
+    bhr_ctx *ctx = new bhr_ctx();
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->cfg = *cfg;
+    ctx->rows = cfg->row1 - cfg->row0;
+    ctx->bloom_R = (int32_t)(cfg->width * 0.02);  // int(self.width * 0.02), render.py:3914
+
+    auto bail = [&](int32_t rc) { bhr_destroy(ctx); return rc; };
+    if (hipSetDevice(cfg->device) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipSetDevice(%d) failed", cfg->device));
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipStreamCreate failed"));
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipEventCreate failed"));
+    for (auto &e : ctx->ring_ev)
+        if (hipEventCreate(&e) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipEventCreate failed"));
+
+    const size_t W = cfg->width, H = cfg->height, rows = ctx->rows, R = ctx->bloom_R;
+    const size_t px3 = rows * W * 3;
+    int32_t rc;
+    if ((rc = dev_alloc(&ctx->d_bg, px3))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_disk, px3))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_blur, px3))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_final, px3))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_final_u8, px3))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_hblur, 3 * (rows + 2 * R) * W))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_wtab, 3 * (R + 1 + 64)))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_wsum_h, 3 * W))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_wsum_v, 3 * H))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_ray_steps, 1))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_queue, 1))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_steps_ring, BHR_TIMING_RING))) return bail(rc);
+    if (hipMemsetAsync(ctx->d_hblur, 0, 3 * (rows + 2 * R) * W * sizeof(float), ctx->stream) != hipSuccess ||
+        hipMemsetAsync(ctx->d_ray_steps, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess)
+        return bail(bhr_fail(BHR_ERR_HIP, "hipMemsetAsync failed"));
+    int32_t v = 0, l = 0;
+    if (bhr_march_resources(&v, &l, cfg->anti_alias != 0) == BHR_OK) {
+        ctx->counters.march_vgprs = v;
+        ctx->counters.march_lds_bytes = l;
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "stream sync failed"));
+    *out = ctx;
+    return BHR_OK;
+}
+
+void bhr_destroy(bhr_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    free_bg(ctx);
+    void *bufs[] = {ctx->d_skybox, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_final_u8, ctx->d_hblur,
+                    ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_queue, ctx->d_noise_in,
+                    ctx->d_noise_out, ctx->d_steps_ring};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ring_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int32_t bhr_sync(bhr_ctx *ctx) {
+    if (!ctx) return bhr_fail(BHR_ERR_INVALID, "null ctx");
+    BHR_TRY(use_device(ctx));
+    BHR_HIP(hipStreamSynchronize(ctx->stream));
+    return BHR_OK;
+}
+
+int32_t bhr_set_skybox(bhr_ctx *ctx, const float *rgb, int32_t tex_h, int32_t tex_w) {
+    if (!ctx || !rgb || tex_h <= 0 || tex_w <= 0) return bhr_fail(BHR_ERR_INVALID, "bhr_set_skybox: bad argument");
+    BHR_TRY(use_device(ctx));
+    if (ctx->d_skybox && (ctx->sky_h != tex_h || ctx->sky_w != tex_w)) {
+        BHR_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_skybox);
+        ctx->d_skybox = nullptr;
+    }
+    if (!ctx->d_skybox) BHR_TRY(dev_alloc(&ctx->d_skybox, (size_t)tex_h * tex_w * 3));
+    ctx->sky_h = tex_h;
+    ctx->sky_w = tex_w;
+    return upload(ctx, ctx->d_skybox, rgb, (size_t)tex_h * tex_w * 3 * sizeof(float));
+}
+
+int32_t bhr_set_disk_texture(bhr_ctx *ctx, const float *rgba, int32_t n_r, int32_t n_phi) {
+    if (!ctx || !rgba || n_r <= 0 || n_phi <= 0) return bhr_fail(BHR_ERR_INVALID, "bhr_set_disk_texture: bad argument");
+    BHR_TRY(use_device(ctx));
+    if (ctx->d_mips && (ctx->n_r != n_r || ctx->n_phi != n_phi))
+        return bhr_fail(BHR_ERR_INVALID, "Texture size mismatch: expected %dx%d, got %dx%d", ctx->n_r, ctx->n_phi, n_r, n_phi);
+    if (!ctx->d_mips) BHR_TRY(alloc_mips(ctx, n_r, n_phi));
+    BHR_TRY(upload(ctx, ctx->d_mips, rgba, (size_t)n_r * n_phi * sizeof(float4)));
+    return bhr_launch_build_mips(ctx);
+}
+
+int32_t bhr_get_disk_texture(bhr_ctx *ctx, float *rgba_out) { return bhr_get_disk_mip(ctx, 0, rgba_out); }
+
+int32_t bhr_get_disk_mip(bhr_ctx *ctx, int32_t level, float *rgba_out) {
+    if (!ctx || !rgba_out) return bhr_fail(BHR_ERR_INVALID, "bhr_get_disk_mip: bad argument");
+    if (!ctx->d_mips) return bhr_fail(BHR_ERR_STATE, "bhr_get_disk_mip: no disk texture");
+    if (level < 0 || level >= BHR_NUM_MIP_LEVELS) return bhr_fail(BHR_ERR_INVALID, "bhr_get_disk_mip: level %d", level);
+    BHR_TRY(use_device(ctx));
+    size_t n = (size_t)ctx->mip_h[level] * ctx->mip_w[level];
+    if (n == 0) return BHR_OK;
+    return download(ctx, rgba_out, ctx->d_mips + ctx->mip_off[level], n * sizeof(float4));
+}
+
+int32_t bhr_num_mip_levels(bhr_ctx *ctx) {
+    if (!ctx || !ctx->d_mips) return 0;
+    int n = 0;
+    for (int l = 0; l < BHR_NUM_MIP_LEVELS; ++l)
+        if (ctx->mip_h[l] > 0 && ctx->mip_w[l] > 0) ++n;
+    return n;
+}
+
+int32_t bhr_bg_init(bhr_ctx *ctx, int32_t n_r, int32_t n_phi, int32_t az_freq, float az_shear, const float *edge,
+                    const float *omega_rows) {
+    if (!ctx || !edge || !omega_rows || n_r <= 0 || n_phi <= 0) return bhr_fail(BHR_ERR_INVALID, "bhr_bg_init: bad argument");
+    BHR_TRY(use_device(ctx));
+    if (ctx->d_mips && (ctx->n_r != n_r || ctx->n_phi != n_phi))
+        return bhr_fail(BHR_ERR_INVALID, "bhr_bg_init: (%d,%d) does not match the disk texture (%d,%d)", n_r, n_phi, ctx->n_r, ctx->n_phi);
+    if (!ctx->d_mips) BHR_TRY(alloc_mips(ctx, n_r, n_phi));
+    const size_t plane = (size_t)n_r * n_phi;
+    if (!ctx->d_comp || ctx->bg_n_r != n_r || ctx->bg_n_phi != n_phi) {
+        BHR_HIP(hipStreamSynchronize(ctx->stream));
+        free_bg(ctx);
+        BHR_TRY(dev_alloc(&ctx->d_comp, 13 * plane));
+        BHR_TRY(dev_alloc(&ctx->d_edge, (size_t)n_r));
+        BHR_TRY(dev_alloc(&ctx->d_omega, (size_t)n_r));
+        BHR_TRY(dev_alloc(&ctx->d_row_stats, (size_t)n_r * 2));
+        BHR_HIP(hipMemsetAsync(ctx->d_comp, 0, 13 * plane * sizeof(float), ctx->stream));
+    }
+    ctx->bg_n_r = n_r;
+    ctx->bg_n_phi = n_phi;
+    ctx->az_freq = az_freq;
+    ctx->az_shear = az_shear;
+    BHR_TRY(upload(ctx, ctx->d_edge, edge, (size_t)n_r * sizeof(float)));
+    BHR_TRY(upload(ctx, ctx->d_omega, omega_rows, (size_t)n_r * sizeof(float)));
+    // initial stats (render.py:3531-3542): stats (0.5, 0.5); row stats from the undisturbed
+    // temp_base profile max(tb, 0.25), max(0.8 tb, 0.10) with tb = clip(1 - r, 0, 1)^1.3 * 0.25
+    ctx->stats[0] = 0.5f;
+    ctx->stats[1] = 0.5f;
+    std::vector<float> rs((size_t)n_r * 2);
+    for (int i = 0; i < n_r; ++i) {
+        double rn = n_r > 1 ? (double)i / (double)(n_r - 1) : 0.0;  // np.linspace(0, 1, n_r)
+        double c = 1.0 - rn;
+        if (c < 0) c = 0;
+        if (c > 1) c = 1;
+        double tb = pow(c, 1.3) * 0.25;
+        double a = tb > 0.25 ? tb : 0.25;
+        double b = tb * 0.8 > 0.10 ? tb * 0.8 : 0.10;
+        rs[(size_t)i * 2 + 0] = (float)a;
+        rs[(size_t)i * 2 + 1] = (float)b;
+    }
+    BHR_TRY(upload(ctx, ctx->d_row_stats, rs.data(), rs.size() * sizeof(float)));
+    ctx->bg_ready = 1;
+    return BHR_OK;
+}
+
+int32_t bhr_generate_background(bhr_ctx *ctx, float t) {
+    if (!ctx) return bhr_fail(BHR_ERR_INVALID, "null ctx");
+    if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call init_background_layer() first");
+    BHR_TRY(use_device(ctx));
+    BHR_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    BHR_TRY(bhr_launch_background(ctx, t));
+    BHR_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+    return BHR_OK;
+}
+
+int32_t bhr_set_entity_staging(bhr_ctx *ctx, const float *staging) {
+    if (!ctx || !staging) return bhr_fail(BHR_ERR_INVALID, "bhr_set_entity_staging: bad argument");
+    if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call init_background_layer() first");
+    BHR_TRY(use_device(ctx));
+    const size_t plane = (size_t)ctx->bg_n_r * ctx->bg_n_phi;
+    return upload(ctx, ctx->d_comp + 5 * plane, staging, 6 * plane * sizeof(float));
+}
+
+int32_t bhr_set_comp(bhr_ctx *ctx, const float *comp13) {
+    if (!ctx || !comp13) return bhr_fail(BHR_ERR_INVALID, "bhr_set_comp: bad argument");
+    if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "bhr_set_comp: call bhr_bg_init first");
+    BHR_TRY(use_device(ctx));
+    const size_t plane = (size_t)ctx->bg_n_r * ctx->bg_n_phi;
+    return upload(ctx, ctx->d_comp, comp13, 13 * plane * sizeof(float));
+}
+
+int32_t bhr_read_comp(bhr_ctx *ctx, float *comp13_out) {
+    if (!ctx || !comp13_out) return bhr_fail(BHR_ERR_INVALID, "bhr_read_comp: bad argument");
+    if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "bhr_read_comp: call bhr_bg_init first");
+    BHR_TRY(use_device(ctx));
+    const size_t plane = (size_t)ctx->bg_n_r * ctx->bg_n_phi;
+    return download(ctx, comp13_out, ctx->d_comp, 13 * plane * sizeof(float));
+}
+
+int32_t bhr_fill_comp_slice(bhr_ctx *ctx, int32_t idx, float value) {
+    if (!ctx || idx < 0 || idx >= 13) return bhr_fail(BHR_ERR_INVALID, "bhr_fill_comp_slice: bad argument");
+    if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "bhr_fill_comp_slice: call bhr_bg_init first");
+    BHR_TRY(use_device(ctx));
+    const size_t plane = (size_t)ctx->bg_n_r * ctx->bg_n_phi;
+    return bhr_launch_fill(ctx, ctx->d_comp + idx * plane, (int64_t)plane, value);
+}
+
+int32_t bhr_set_compose_stats(bhr_ctx *ctx, float density_p98, float struct_scale, const float *row_stats) {
+    if (!ctx || !row_stats) return bhr_fail(BHR_ERR_INVALID, "bhr_set_compose_stats: bad argument");
+    if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "bhr_set_compose_stats: call bhr_bg_init first");
+    BHR_TRY(use_device(ctx));
+    ctx->stats[0] = density_p98;
+    ctx->stats[1] = struct_scale;
+    return upload(ctx, ctx->d_row_stats, row_stats, (size_t)ctx->bg_n_r * 2 * sizeof(float));
+}
+
+int32_t bhr_compose_texture(bhr_ctx *ctx, float t_offset, int32_t enable_rt, float color_temp) {
+    if (!ctx) return bhr_fail(BHR_ERR_INVALID, "null ctx");
+    if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call upload_parametric_state() / init_background_layer() before composing");
+    BHR_TRY(use_device(ctx));
+    BHR_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
+    BHR_TRY(bhr_launch_compose(ctx, t_offset, enable_rt, color_temp));
+    BHR_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+    return BHR_OK;
+}
+
+int32_t bhr_eval_noise(bhr_ctx *ctx, const float *coords, int64_t n, int32_t mode, int32_t octaves,
+                       float persistence, float lacunarity, float *out) {
+    if (!ctx || !coords || !out || n < 0) return bhr_fail(BHR_ERR_INVALID, "bhr_eval_noise: bad argument");
+    if (n == 0) return BHR_OK;
+    BHR_TRY(use_device(ctx));
+    if (ctx->noise_cap < n) {
+        BHR_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_noise_in) (void)hipFree(ctx->d_noise_in);
+        if (ctx->d_noise_out) (void)hipFree(ctx->d_noise_out);
+        ctx->d_noise_in = ctx->d_noise_out = nullptr;
+        ctx->noise_cap = 0;
+        BHR_TRY(dev_alloc(&ctx->d_noise_in, (size_t)n * 3));
+        BHR_TRY(dev_alloc(&ctx->d_noise_out, (size_t)n));
+        ctx->noise_cap = n;
+    }
+    BHR_TRY(upload(ctx, ctx->d_noise_in, coords, (size_t)n * 3 * sizeof(float)));
+    BHR_TRY(bhr_launch_noise(ctx, n, mode, octaves, persistence, lacunarity));
+    return download(ctx, out, ctx->d_noise_out, (size_t)n * sizeof(float));
+}
+
+int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
+    if (!ctx || !cam) return bhr_fail(BHR_ERR_INVALID, "bhr_render: null argument");
+    BHR_TRY(use_device(ctx));
+    const int slot = (int)(ctx->ring_head % BHR_TIMING_RING);
+    ctx->cur_slot = slot;
+    BHR_TRY(bhr_launch_march(ctx, cam, flags));  // records ev[0]/ev[1] and the ring's march events
+    const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
+    if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctx));
+    BHR_TRY(bhr_launch_bloom_v(ctx, with_bloom));
+    BHR_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    BHR_HIP(hipEventRecord(ctx->ring_ev[slot * 3 + 2], ctx->stream));
+    ctx->ring_head += 1;
+    ctx->last_flags = (int32_t)flags;
+    ctx->timing_valid = 1;
+    return BHR_OK;
+}
+
+int32_t bhr_read_layer(bhr_ctx *ctx, int32_t layer, float *out) {
+    if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_read_layer: bad argument");
+    BHR_TRY(use_device(ctx));
+    const float *src = nullptr;
+    switch (layer) {
+        case BHR_LAYER_FINAL: src = ctx->d_final; break;
+        case BHR_LAYER_BG: src = ctx->d_bg; break;
+        case BHR_LAYER_DISK: src = ctx->d_disk; break;
+        case BHR_LAYER_BLUR: src = ctx->d_blur; break;
+        default: return bhr_fail(BHR_ERR_INVALID, "bhr_read_layer: unknown layer %d", layer);
+    }
+    return download(ctx, out, src, (size_t)ctx->rows * ctx->cfg.width * 3 * sizeof(float));
+}
+
+int32_t bhr_read_final_u8(bhr_ctx *ctx, uint8_t *out) {
+    if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_read_final_u8: bad argument");
+    BHR_TRY(use_device(ctx));
+    const long long n = (long long)ctx->rows * ctx->cfg.width * 3;
+    hipLaunchKernelGGL(quantize_u8_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->d_final, ctx->d_final_u8, n);
+    BHR_HIP(hipGetLastError());
+    return download(ctx, out, ctx->d_final_u8, (size_t)n);
+}
+
+int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {
+    if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_get_counters: bad argument");
+    BHR_TRY(use_device(ctx));
+    BHR_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->timing_valid) {
+        unsigned long long steps = 0;
+        BHR_HIP(hipMemcpy(&steps, ctx->last_steps_ptr ? ctx->last_steps_ptr : ctx->d_ray_steps, sizeof(steps), hipMemcpyDeviceToHost));
+        ctx->counters.ray_steps = steps;
+        ctx->counters.march_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+        ctx->counters.bloom_ms = ev_ms(ctx->ev[1], ctx->ev[2]);
+        ctx->counters.frame_ms = ev_ms(ctx->ev[0], ctx->ev[2]);
+    }
+    {
+        const int64_t n = ctx->ring_head < BHR_TIMING_RING ? ctx->ring_head : BHR_TIMING_RING;
+        float ms_m = 0.0f, ms_b = 0.0f;
+        unsigned long long steps_sum = 0;
+        if (n > 0) {
+            std::vector<unsigned long long> hs(BHR_TIMING_RING);
+            BHR_HIP(hipMemcpy(hs.data(), ctx->d_steps_ring, sizeof(unsigned long long) * BHR_TIMING_RING, hipMemcpyDeviceToHost));
+            for (int64_t k = 0; k < n; ++k) {
+                const int slot = (int)((ctx->ring_head - 1 - k) % BHR_TIMING_RING);
+                ms_m += ev_ms(ctx->ring_ev[slot * 3 + 0], ctx->ring_ev[slot * 3 + 1]);
+                ms_b += ev_ms(ctx->ring_ev[slot * 3 + 1], ctx->ring_ev[slot * 3 + 2]);
+                steps_sum += hs[slot];
+            }
+        }
+        ctx->counters.frames_timed = (int32_t)n;
+        ctx->counters.march_ms_sum = ms_m;
+        ctx->counters.bloom_ms_sum = ms_b;
+        ctx->counters.ray_steps_sum = steps_sum;
+    }
+    if (ctx->bg_ready) {
+        if (hipEventQuery(ctx->ev[5]) == hipSuccess) ctx->counters.background_ms = ev_ms(ctx->ev[4], ctx->ev[5]);
+        if (hipEventQuery(ctx->ev[7]) == hipSuccess) ctx->counters.compose_ms = ev_ms(ctx->ev[6], ctx->ev[7]);
+    }
+    *out = ctx->counters;
+    return BHR_OK;
+}
+
+int32_t bhr_timing_reset(bhr_ctx *ctx) {
+    if (!ctx) return bhr_fail(BHR_ERR_INVALID, "null ctx");
+    BHR_TRY(use_device(ctx));
+    BHR_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->ring_head = 0;
+    return BHR_OK;
+}
+
+int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host) {
+    if (!ctxs || n <= 0 || !cam) return bhr_fail(BHR_ERR_INVALID, "bhr_group_render: bad argument");
+    const int W = ctxs[0]->cfg.width, H = ctxs[0]->cfg.height;
+    int expect = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!ctxs[k]) return bhr_fail(BHR_ERR_INVALID, "bhr_group_render: null ctx %d", k);
+        if (ctxs[k]->cfg.width != W || ctxs[k]->cfg.height != H || ctxs[k]->cfg.row0 != expect)
+            return bhr_fail(BHR_ERR_INVALID, "bhr_group_render: tile %d does not continue the image (row0 %d, expected %d)", k, ctxs[k]->cfg.row0, expect);
+        expect = ctxs[k]->cfg.row1;
+    }
+    if (expect != H) return bhr_fail(BHR_ERR_INVALID, "bhr_group_render: tiles cover %d of %d rows", expect, H);
+    const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
+    const size_t R = ctxs[0]->bloom_R;
+
+    // phase 1: every tile marches and H-blurs its own rows, concurrently
+    for (int k = 0; k < n; ++k) {
+        BHR_TRY(use_device(ctxs[k]));
+        ctxs[k]->cur_slot = -1;
+        BHR_TRY(bhr_launch_march(ctxs[k], cam, flags));
+        if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctxs[k]));
+        BHR_HIP(hipEventRecord(ctxs[k]->ev[3], ctxs[k]->stream));
+    }
+    // phase 2: halo exchange of the H-blurred rows (planar (3, rows + 2R, W)); the V pass of
+    // tile k needs up to R rows from each neighbour.  Peer copies ride the receiving stream
+    // after the producer's event.
+    if (with_bloom && n > 1) {
+        for (int k = 0; k < n; ++k) {
+            bhr_ctx *me = ctxs[k];
+            BHR_TRY(use_device(me));
+            const size_t my_rows = me->rows;
+            for (int side = 0; side < 2; ++side) {
+                // side 0: rows above me come from tiles k-1, k-2, ...; side 1: below
+                size_t need = R, got = 0;
+                int q = side == 0 ? k - 1 : k + 1;
+                while (need > 0 && q >= 0 && q < n) {
+                    bhr_ctx *nb = ctxs[q];
+                    const size_t take = nb->rows < need ? nb->rows : need;
+                    BHR_HIP(hipStreamWaitEvent(me->stream, nb->ev[3], 0));
+                    for (int c = 0; c < 3; ++c) {
+                        const size_t nb_plane = (size_t)(nb->rows + 2 * R) * W, my_plane = (my_rows + 2 * R) * W;
+                        // neighbour's own rows live at [R, R + nb->rows)
+                        size_t src_row = side == 0 ? R + nb->rows - take : R;
+                        size_t dst_row = side == 0 ? R - got - take : R + my_rows + got;
+                        BHR_HIP(hipMemcpyPeerAsync(me->d_hblur + c * my_plane + dst_row * W, me->cfg.device,
+                                                   nb->d_hblur + c * nb_plane + src_row * W, nb->cfg.device,
+                                                   take * W * sizeof(float), me->stream));
+                    }
+                    need -= take;
+                    got += take;
+                    q += side == 0 ? -1 : 1;
+                }
+            }
+        }
+    }
+    // phase 3: V pass + combine per tile
+    for (int k = 0; k < n; ++k) {
+        BHR_TRY(use_device(ctxs[k]));
+        BHR_TRY(bhr_launch_bloom_v(ctxs[k], with_bloom));
+        BHR_HIP(hipEventRecord(ctxs[k]->ev[2], ctxs[k]->stream));
+        ctxs[k]->last_flags = (int32_t)flags;
+        ctxs[k]->timing_valid = 1;
+    }
+    // phase 4: gather the final tiles
+    if (out_host) {
+        for (int k = 0; k < n; ++k) {
+            BHR_TRY(use_device(ctxs[k]));
+            BHR_HIP(hipMemcpyAsync(out_host + (size_t)ctxs[k]->cfg.row0 * W * 3, ctxs[k]->d_final,
+                                   (size_t)ctxs[k]->rows * W * 3 * sizeof(float), hipMemcpyDeviceToHost, ctxs[k]->stream));
+        }
+    }
+    for (int k = 0; k < n; ++k) {
+        BHR_TRY(use_device(ctxs[k]));
+        BHR_HIP(hipStreamSynchronize(ctxs[k]->stream));
+    }
+    return BHR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// bhr_internal.h -- shared declarations of libbhr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bhr.h"
+
+#define BHR_NUM_MIP_LEVELS 5  // generate_disk_mipmaps(levels=4) => 5 stored levels (render.py:2239-2240)
+#define BHR_WAVE 64
+
+// ---- constants of the reference (render.py:37-59) ---------------------------
+#define BHR_RS 1.0f
+#define BHR_G_FACTOR_CAP 1.5f
+#define BHR_G_LUMINOSITY_POWER 1.5f
+#define BHR_G_BRIGHTNESS_GAIN 0.38f
+#define BHR_DISK_COLOR_TEMPERATURE 6000.0f
+#define BHR_DISK_ALPHA_GAIN 6.0f
+#define BHR_DISK_RADIAL_BRIGHTNESS_POWER 1.2f
+#define BHR_DISK_RADIAL_BRIGHTNESS_MIN 0.2f
+#define BHR_DISK_RADIAL_BRIGHTNESS_MAX 8.0f
+
+#define BHR_PI_F 3.14159274101257324f      // (float)pi
+#define BHR_TWO_PI_F 6.28318548202514648f  // (float)(2*pi)
+
+// Scene textures as the march kernel sees them.
+struct BhrScene {
+    const float *skybox;   // (sky_h, sky_w, 3)
+    int32_t sky_h, sky_w;
+    const float4 *mips;    // packed levels 0..4, level l at mip_off[l], dims (mip_h[l], mip_w[l])
+    int32_t mip_off[BHR_NUM_MIP_LEVELS];
+    int32_t mip_h[BHR_NUM_MIP_LEVELS];
+    int32_t mip_w[BHR_NUM_MIP_LEVELS];
+    int32_t n_r, n_phi;
+};
+
+// Kernel argument block of the march (passed by value -> SGPRs).
+struct BhrMarchArgs {
+    float cp[3], cr[3], cu[3], cf[3];
+    float pw, ph, r_esc;
+    float h_base, r_inner, r_outer, t_offset;
+    float tilt_rad, tan_t, sin_t, cos_t;
+    float aa_strength;
+    float max_affine;
+    int32_t max_iter;
+    int32_t width, height;   // full image
+    int32_t row0, rows;      // this context's row block
+    BhrScene sc;
+    float *bg;               // (rows, width, 3)
+    float *disk;             // (rows, width, 3)
+    unsigned long long *ray_steps;
+    unsigned int *queue;     // persistent-wave work counter (zeroed before launch)
+    int32_t n_tiles;         // 8x8 pixel tiles in the row block
+    int32_t tiles_x;
+};
+
+struct bhr_ctx {
+    bhr_config cfg;
+    int32_t rows;
+    hipStream_t stream;
+    hipEvent_t ev[8];
+    // per-frame timing ring: 3 events per bhr_render (march start, march end, frame end)
+    hipEvent_t ring_ev[BHR_TIMING_RING * 3];
+    unsigned long long *d_steps_ring;   // one ray-step counter per ring slot
+    int64_t ring_head;                  // frames recorded since reset
+    unsigned long long *last_steps_ptr; // counter the last march accumulated into
+    int32_t cur_slot;                   // ring slot of the bhr_render in flight (-1: untimed launch)
+
+    // scene
+    float *d_skybox;
+    int32_t sky_h, sky_w;
+    float4 *d_mips;
+    int32_t n_r, n_phi;
+    int32_t mip_off[BHR_NUM_MIP_LEVELS], mip_h[BHR_NUM_MIP_LEVELS], mip_w[BHR_NUM_MIP_LEVELS];
+    int64_t mip_texels;
+
+    // texture pipeline
+    int32_t bg_ready, bg_n_r, bg_n_phi, az_freq;
+    float az_shear;
+    float *d_comp;       // (13, n_r, n_phi)
+    float *d_edge, *d_omega, *d_row_stats;
+    float stats[2];
+    float *d_noise_in, *d_noise_out;
+    int64_t noise_cap;
+
+    // frame buffers for rows [row0,row1)
+    float *d_bg, *d_disk;      // (rows, W, 3)
+    float *d_hblur;            // planar (3, rows + 2R, W): rows [row0-R, row1+R)
+    float *d_blur;             // (rows, W, 3)
+    float *d_final;            // (rows, W, 3)
+    uint8_t *d_final_u8;       // (rows, W, 3)
+    float *d_wtab;             // bloom weights (3, R + pad)
+    float *d_wsum_h;           // (3, W)
+    float *d_wsum_v;           // (3, H)
+    int32_t bloom_R, bloom_ready;
+    unsigned long long *d_ray_steps;
+    unsigned int *d_queue;
+    float *h_pinned;           // staging for readbacks
+    size_t h_pinned_bytes;
+
+    bhr_counters counters;
+    int32_t last_flags;
+    int32_t timing_valid;
+};
+
+// error plumbing (api.hip)
+int32_t bhr_fail(int32_t code, const char *fmt, ...);
+#define BHR_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return bhr_fail(BHR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                            __FILE__, __LINE__);                                            \
+    } while (0)
+
+// launchers (each lives next to its kernels)
+int32_t bhr_launch_march(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);
+int32_t bhr_bloom_prepare(bhr_ctx *ctx);
+int32_t bhr_launch_bloom_h(bhr_ctx *ctx);
+int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom);
+int32_t bhr_launch_build_mips(bhr_ctx *ctx);
+int32_t bhr_launch_background(bhr_ctx *ctx, float t);
+int32_t bhr_launch_compose(bhr_ctx *ctx, float t_offset, int32_t enable_rt, float color_temp);
+int32_t bhr_launch_copy_staging(bhr_ctx *ctx, const float *d_staging);
+int32_t bhr_launch_fill(bhr_ctx *ctx, float *dst, int64_t n, float v);
+int32_t bhr_launch_noise(bhr_ctx *ctx, int64_t n, int32_t mode, int32_t octaves, float pers, float lac);
+int32_t bhr_march_resources(int32_t *vgprs, int32_t *lds, int32_t diff);

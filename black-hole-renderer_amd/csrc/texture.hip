@@ -1,0 +1,322 @@
+// texture.hip -- procedural disk-texture pipeline on gfx950.
+//
+//   simplex / FBM           render.py:2642-2785  (Gustavson 3-D simplex, Perlin
+//                           perm[512], with the reference's gradient quirks)
+//   background generator    render.py:3332-3451  (42 simplex evaluations / texel)
+//   compose                 render.py:3169-3257  (13 components -> RGBA)
+//   mip chain               render.py:3261-3283  (2x2 box, floor halving)
+//   noise evaluation        render.py:3305-3326
+//
+// The background kernel is ALU bound (the permutation table lives in LDS); the
+// compose kernel is a 52 B in / 16 B out per texel stream and writes straight
+// into level 0 of the packed mip stack, so the reference's copy-base kernel
+// (render.py:3261-3265) has no counterpart here.
+#include "bhr_internal.h"
+
+namespace {
+
+__constant__ int c_perm256[256] = {
+    151,160,137,91,90,15,131,13,201,95,96,53,194,233,7,225,
+    140,36,103,30,69,142,8,99,37,240,21,10,23,190,6,148,
+    247,120,234,75,0,26,197,62,94,252,219,203,117,35,11,32,
+    57,177,33,88,237,149,56,87,174,20,125,136,171,168,68,175,
+    74,165,71,134,139,48,27,166,77,146,158,231,83,111,229,122,
+    60,211,133,230,220,105,92,41,55,46,245,40,244,102,143,54,
+    65,25,63,161,1,216,80,73,209,76,132,187,208,89,18,169,
+    200,196,135,130,116,188,159,86,164,100,109,198,173,186,3,64,
+    52,217,226,250,124,123,5,202,38,147,118,126,255,82,85,212,
+    207,206,59,227,47,16,58,17,182,189,28,42,223,183,170,213,
+    119,248,152,2,44,154,163,70,221,153,101,155,167,43,172,9,
+    129,22,39,253,19,98,108,110,79,113,224,232,178,185,112,104,
+    218,246,97,228,251,34,242,193,238,210,144,12,191,179,162,241,
+    81,51,145,235,249,14,239,107,49,192,214,31,181,199,106,157,
+    184,84,204,176,115,121,50,45,127,4,150,254,138,236,205,93,
+    222,114,67,29,24,72,243,141,128,195,78,66,215,61,156,180,
+};
+
+// perm_field = _perm + _perm (512 entries, render.py:2287-2288) staged in LDS.
+__device__ __forceinline__ void load_perm(int *perm) {
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) perm[k] = c_perm256[k & 255];
+    __syncthreads();
+}
+
+// _grad3_dot (render.py:2642-2660): h = hash % 12 so the "h == 12 or 14" arm is dead.
+__device__ __forceinline__ float grad3_dot(int hash_val, float x, float y, float z) {
+    int h = hash_val % 12;  // hash_val >= 0
+    float u = h < 8 ? x : y;
+    float v = h < 4 ? y : z;
+    float r1 = (h & 1) == 0 ? u : -u;
+    float r2 = (h & 2) == 0 ? v : -v;
+    return r1 + r2;
+}
+
+// _simplex_noise_3d (render.py:2662-2750)
+__device__ __forceinline__ float simplex3(const int *perm, float x, float y, float z) {
+    const float F3 = 1.0f / 3.0f;
+    const float G3 = 1.0f / 6.0f;
+    float s = (x + y + z) * F3;
+    int i = (int)floorf(x + s);
+    int j = (int)floorf(y + s);
+    int k = (int)floorf(z + s);
+    float t = (float)(i + j + k) * G3;
+    float x0 = x - ((float)i - t);
+    float y0 = y - ((float)j - t);
+    float z0 = z - ((float)k - t);
+    int i1, j1, k1, i2, j2, k2;
+    if (x0 >= y0) {
+        if (y0 >= z0)      { i1 = 1; j1 = 0; k1 = 0; i2 = 1; j2 = 1; k2 = 0; }
+        else if (x0 >= z0) { i1 = 1; j1 = 0; k1 = 0; i2 = 1; j2 = 0; k2 = 1; }
+        else               { i1 = 0; j1 = 0; k1 = 1; i2 = 1; j2 = 0; k2 = 1; }
+    } else {
+        if (y0 < z0)       { i1 = 0; j1 = 0; k1 = 1; i2 = 0; j2 = 1; k2 = 1; }
+        else if (x0 < z0)  { i1 = 0; j1 = 1; k1 = 0; i2 = 0; j2 = 1; k2 = 1; }
+        else               { i1 = 0; j1 = 1; k1 = 0; i2 = 1; j2 = 1; k2 = 0; }
+    }
+    float x1 = x0 - (float)i1 + G3, y1 = y0 - (float)j1 + G3, z1 = z0 - (float)k1 + G3;
+    float x2 = x0 - (float)i2 + 2.0f * G3, y2 = y0 - (float)j2 + 2.0f * G3, z2 = z0 - (float)k2 + 2.0f * G3;
+    float x3 = x0 - 1.0f + 3.0f * G3, y3 = y0 - 1.0f + 3.0f * G3, z3 = z0 - 1.0f + 3.0f * G3;
+    int ii = i & 255, jj = j & 255, kk = k & 255;
+    int pk0 = perm[kk], pk1 = perm[kk + 1];
+    int gi0 = perm[ii + perm[jj + pk0]];
+    int gi1 = perm[ii + i1 + perm[jj + j1 + (k1 ? pk1 : pk0)]];
+    int gi2 = perm[ii + i2 + perm[jj + j2 + (k2 ? pk1 : pk0)]];
+    int gi3 = perm[ii + 1 + perm[jj + 1 + pk1]];
+    float n = 0.0f;
+    float t0 = 0.6f - x0 * x0 - y0 * y0 - z0 * z0;
+    if (t0 >= 0.0f) { t0 = t0 * t0; n += t0 * t0 * grad3_dot(gi0, x0, y0, z0); }
+    float t1 = 0.6f - x1 * x1 - y1 * y1 - z1 * z1;
+    if (t1 >= 0.0f) { t1 = t1 * t1; n += t1 * t1 * grad3_dot(gi1, x1, y1, z1); }
+    float t2 = 0.6f - x2 * x2 - y2 * y2 - z2 * z2;
+    if (t2 >= 0.0f) { t2 = t2 * t2; n += t2 * t2 * grad3_dot(gi2, x2, y2, z2); }
+    float t3 = 0.6f - x3 * x3 - y3 * y3 - z3 * z3;
+    if (t3 >= 0.0f) { t3 = t3 * t3; n += t3 * t3 * grad3_dot(gi3, x3, y3, z3); }
+    return 32.0f * n;
+}
+
+// _fbm_3d (render.py:2752-2785)
+template <int OCT>
+__device__ __forceinline__ float fbm3(const int *perm, float x, float y, float z, float persistence,
+                                      float lacunarity) {
+    float value = 0.0f, amplitude = 1.0f, freq = 1.0f;
+#pragma unroll
+    for (int o = 0; o < OCT; ++o) {
+        value += amplitude * simplex3(perm, x * freq, y * freq, z * freq);
+        amplitude *= persistence;
+        freq *= lacunarity;
+    }
+    return value;
+}
+__device__ float fbm3_dyn(const int *perm, float x, float y, float z, int octaves, float persistence,
+                          float lacunarity) {
+    float value = 0.0f, amplitude = 1.0f, freq = 1.0f;
+    for (int o = 0; o < octaves; ++o) {
+        value += amplitude * simplex3(perm, x * freq, y * freq, z * freq);
+        amplitude *= persistence;
+        freq *= lacunarity;
+    }
+    return value;
+}
+
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+// _generate_background_kernel (render.py:3332-3451); writes comp[0,1,2,3,4,11,12].
+__global__ __launch_bounds__(256) void background_kernel(float *__restrict__ comp, int n_r, int n_phi, int az_freq,
+                                                         float az_shear, float r_inner, float r_outer, float t) {
+    __shared__ int perm[512];
+    load_perm(perm);
+    const int phi_i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ri = blockIdx.y;
+    if (phi_i >= n_phi) return;
+    const size_t plane = (size_t)n_r * n_phi;
+    const size_t q = (size_t)ri * n_phi + phi_i;
+    const float pi2 = 2.0f * BHR_PI_F;
+
+    float r = (float)ri / (float)n_r;
+    float phi = (float)phi_i / (float)n_phi * pi2;
+    float r_phys = r_inner + (r_outer - r_inner) * r;
+    float omega = sqrtf(0.5f / (r_phys * r_phys * r_phys + 1e-6f));
+    float phi_rot = phi + omega * t;
+    float cx = cosf(phi_rot);
+    float cy = sinf(phi_rot);
+
+    float decay = powf(fmaxf(1.0f - r, 0.0f), 1.3f);
+    float tb_noise = clamp01(0.5f + 0.5f * fbm3<4>(perm, cx * 8.0f, cy * 8.0f, r * 8.0f + t * 0.05f, 0.6f, 2.0f));
+    comp[0 * plane + q] = decay * (0.85f + 0.15f * tb_noise) * 0.25f;
+    comp[1 * plane + q] = 0.0f;
+    comp[2 * plane + q] = 0.0f;
+
+    float t_coarse = clamp01(0.5f + 0.5f * fbm3<3>(perm, cx * 8.0f, cy * 8.0f, r * 4.0f + t * 0.06f, 0.45f, 2.0f)) * 0.08f;
+    float t_mid = clamp01(0.5f + 0.5f * fbm3<4>(perm, cx * 24.0f, cy * 24.0f, r * 12.0f + t * 0.08f, 0.45f, 2.0f)) * 0.15f;
+    float t_fine = clamp01(0.5f + 0.5f * fbm3<5>(perm, cx * 80.0f, cy * 80.0f, r * 40.0f + t * 0.1f, 0.45f, 2.0f)) * 0.25f;
+    float t_extra = clamp01(0.5f + 0.5f * fbm3<4>(perm, cx * 200.0f, cy * 200.0f, r * 100.0f + t * 0.12f, 0.4f, 2.0f)) * 0.22f;
+    float t_ultra = clamp01(0.5f + 0.5f * fbm3<3>(perm, cx * 400.0f, cy * 400.0f, r * 200.0f + t * 0.15f, 0.35f, 2.0f)) * 0.18f;
+    float t_pixel = clamp01(simplex3(perm, cx * 800.0f, cy * 800.0f, r * 400.0f + t * 0.2f)) * 0.12f;
+    float turb = clamp01(t_coarse + t_mid + t_fine + t_extra + t_ultra + t_pixel);
+    comp[3 * plane + q] = turb;
+    comp[4 * plane + q] = 0.05f * turb;
+
+    float shear = powf(r, 1.2f) * az_shear;
+    float az_wave = 0.5f + 0.5f * sinf((phi_rot + shear) * (float)az_freq);
+    float az_n = clamp01(0.5f + 0.5f * fbm3<3>(perm, cx * 3.0f, cy * 3.0f, r * 3.0f + t * 0.04f, 0.5f, 2.0f));
+    comp[11 * plane + q] = az_wave * az_n;
+
+    float d_coarse = clamp01(0.5f + 0.5f * fbm3<3>(perm, cx * 8.0f, cy * 8.0f, r * 4.0f + t * 0.003f, 0.5f, 2.0f)) * 0.05f;
+    float d_mid = clamp01(0.5f + 0.5f * fbm3<3>(perm, cx * 32.0f, cy * 32.0f, r * 16.0f + t * 0.005f, 0.5f, 2.0f)) * 0.15f;
+    float d_fine = clamp01(0.5f + 0.5f * fbm3<4>(perm, cx * 100.0f, cy * 100.0f, r * 50.0f + t * 0.006f, 0.45f, 2.0f)) * 0.30f;
+    float d_extra = clamp01(0.5f + 0.5f * fbm3<4>(perm, cx * 250.0f, cy * 250.0f, r * 125.0f + t * 0.008f, 0.4f, 2.0f)) * 0.30f;
+    float d_pixel = clamp01(simplex3(perm, cx * 500.0f, cy * 500.0f, r * 250.0f + t * 0.01f)) * 0.20f;
+    float disturb_raw = (d_coarse + d_mid + d_fine + d_extra + d_pixel) * 1.4f;
+    disturb_raw = fminf(fmaxf(disturb_raw, 0.05f), 1.0f);
+    float radial_preserve = 0.6f + 0.4f * r;
+    comp[12 * plane + q] = fminf(fmaxf(disturb_raw * radial_preserve, 0.1f), 1.0f);
+}
+
+// _color_temp_to_tint (render.py:2407-2437), general temperature
+__device__ __forceinline__ void color_temp_to_tint(float temp, float &r, float &g, float &b) {
+    float t = temp / 100.0f;
+    r = 1.0f;
+    if (t > 66.0f) r = fminf(fmaxf(1.292936f * powf(fmaxf(t - 60.0f, 0.0001f), -0.1332047592f), 0.0f), 1.0f);
+    if (t <= 66.0f)
+        g = fminf(fmaxf(0.390082f * logf(fmaxf(t, 0.0001f)) - 0.631841f, 0.0f), 1.0f);
+    else
+        g = fminf(fmaxf(1.129891f * powf(fmaxf(t - 60.0f, 0.0001f), -0.0755148492f), 0.0f), 1.0f);
+    b = 1.0f;
+    if (t < 66.0f) {
+        if (t <= 19.0f)
+            b = 0.0f;
+        else
+            b = fminf(fmaxf(0.543207f * logf(fmaxf(t - 10.0f, 0.0001f)) - 1.19625f, 0.0f), 1.0f);
+    }
+}
+
+// _compose_disk_texture_kernel (render.py:3169-3257)
+__global__ __launch_bounds__(256) void compose_kernel(float4 *__restrict__ tex, const float *__restrict__ comp,
+                                                      const float *__restrict__ omega, const float *__restrict__ edge,
+                                                      const float *__restrict__ row_stats, float density_p98,
+                                                      float struct_scale, int n_r, int n_phi, float t_offset,
+                                                      int enable_rt, float color_temp_val) {
+    const int phi_i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ri = blockIdx.y;
+    if (phi_i >= n_phi) return;
+    const size_t plane = (size_t)n_r * n_phi;
+
+    float t_factor = (color_temp_val - 4500.0f) / (6500.0f - 2700.0f);
+    float T_min = 2000.0f + t_factor * 1000.0f;
+    float T_max = 9000.0f + t_factor * 3000.0f;
+    float rt_w = enable_rt == 0 ? 0.0f : 0.20f;
+
+    float omega_val = omega[ri];
+    int shift = (int)(t_offset * omega_val / (2.0f * BHR_PI_F) * (float)n_phi);
+    int src = (phi_i + shift) % n_phi;
+    if (src < 0) src += n_phi;
+    const size_t q = (size_t)ri * n_phi + src;
+
+    float tb = comp[0 * plane + q], sp = comp[1 * plane + q], sp_t = comp[2 * plane + q];
+    float turb = comp[3 * plane + q], turb_t = comp[4 * plane + q];
+    float arc = comp[5 * plane + q], arc_t = comp[6 * plane + q];
+    float rt = comp[7 * plane + q], rt_t = comp[8 * plane + q];
+    float hs = comp[9 * plane + q], hs_t = comp[10 * plane + q];
+    float az = comp[11 * plane + q], dm = comp[12 * plane + q];
+
+    float density = (0.15f + 0.10f * sp + 0.30f * turb + 0.20f * hs + 0.30f * arc + rt_w * rt) * dm * edge[ri];
+    density = fminf(fmaxf(density / (density_p98 + 1e-6f), 0.0f), 1.0f);
+
+    float temp_struct = (sp_t + turb_t + arc_t + rt_t + hs_t) * dm;
+    float ts_scaled = fminf(fmaxf(temp_struct / (struct_scale + 1e-6f) * 0.8f, 0.0f), 1.2f);
+
+    float max_r = row_stats[ri * 2 + 0];
+    float p70_r = row_stats[ri * 2 + 1];
+    float ceiling = fmaxf(p70_r, 0.05f);
+    float tb_clamped = fminf(fminf(tb, ceiling), max_r);
+
+    float temperature = fminf(fmaxf(fmaxf(tb_clamped, ts_scaled), 0.0f), 1.0f);
+    float temp_aniso = fminf(fmaxf(temperature * (0.9f + 0.25f * az), 0.0f), 1.0f);
+    float T_K = T_min + temp_aniso * (T_max - T_min);
+    float bb_r, bb_g, bb_b;
+    color_temp_to_tint(T_K, bb_r, bb_g, bb_b);
+    bb_b = fminf(bb_b, bb_r);
+    float lum = fminf(fmaxf(sqrtf(temp_aniso), 0.0f), 1.0f);
+
+    tex[(size_t)ri * n_phi + phi_i] = make_float4(fminf(fmaxf(bb_r * lum, 0.0f), 1.0f), fminf(fmaxf(bb_g * lum, 0.0f), 1.0f),
+                                                  fminf(fmaxf(bb_b * lum, 0.0f), 1.0f), density);
+}
+
+// _mipmap_downsample_kernel (render.py:3269-3281) on the packed stack
+__global__ __launch_bounds__(256) void mip_down_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                       int src_w, int dst_h, int dst_w) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ri = blockIdx.y;
+    if (pi >= dst_w || ri >= dst_h) return;
+    float4 a = src[(size_t)(ri * 2) * src_w + pi * 2];
+    float4 b = src[(size_t)(ri * 2) * src_w + pi * 2 + 1];
+    float4 c = src[(size_t)(ri * 2 + 1) * src_w + pi * 2];
+    float4 d = src[(size_t)(ri * 2 + 1) * src_w + pi * 2 + 1];
+    dst[(size_t)ri * dst_w + pi] = make_float4((a.x + b.x + c.x + d.x) / 4.0f, (a.y + b.y + c.y + d.y) / 4.0f,
+                                               (a.z + b.z + c.z + d.z) / 4.0f, (a.w + b.w + c.w + d.w) / 4.0f);
+}
+
+// _noise_eval_kernel (render.py:3305-3326)
+__global__ __launch_bounds__(256) void noise_eval_kernel(const float *__restrict__ coords, float *__restrict__ out,
+                                                         long long n, int mode, int octaves, float persistence,
+                                                         float lacunarity) {
+    __shared__ int perm[512];
+    load_perm(perm);
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float cx = coords[i * 3 + 0], cy = coords[i * 3 + 1], cz = coords[i * 3 + 2];
+    out[i] = mode == 0 ? simplex3(perm, cx, cy, cz) : fbm3_dyn(perm, cx, cy, cz, octaves, persistence, lacunarity);
+}
+
+__global__ void fill_kernel(float *dst, long long n, float v) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = v;
+}
+
+}  // namespace
+
+int32_t bhr_launch_build_mips(bhr_ctx *ctx) {
+    for (int l = 1; l < BHR_NUM_MIP_LEVELS; ++l) {
+        int dh = ctx->mip_h[l], dw = ctx->mip_w[l];
+        if (dh <= 0 || dw <= 0) continue;
+        dim3 grid((dw + 255) / 256, dh), block(256);
+        hipLaunchKernelGGL(mip_down_kernel, grid, block, 0, ctx->stream, ctx->d_mips + ctx->mip_off[l - 1],
+                           ctx->d_mips + ctx->mip_off[l], ctx->mip_w[l - 1], dh, dw);
+    }
+    BHR_HIP(hipGetLastError());
+    return BHR_OK;
+}
+
+int32_t bhr_launch_background(bhr_ctx *ctx, float t) {
+    dim3 grid((ctx->bg_n_phi + 255) / 256, ctx->bg_n_r), block(256);
+    hipLaunchKernelGGL(background_kernel, grid, block, 0, ctx->stream, ctx->d_comp, ctx->bg_n_r, ctx->bg_n_phi,
+                       ctx->az_freq, ctx->az_shear, ctx->cfg.r_disk_inner, ctx->cfg.r_disk_outer, t);
+    BHR_HIP(hipGetLastError());
+    return BHR_OK;
+}
+
+int32_t bhr_launch_compose(bhr_ctx *ctx, float t_offset, int32_t enable_rt, float color_temp) {
+    dim3 grid((ctx->n_phi + 255) / 256, ctx->n_r), block(256);
+    hipLaunchKernelGGL(compose_kernel, grid, block, 0, ctx->stream, ctx->d_mips, ctx->d_comp, ctx->d_omega,
+                       ctx->d_edge, ctx->d_row_stats, ctx->stats[0], ctx->stats[1], ctx->n_r, ctx->n_phi, t_offset,
+                       enable_rt, color_temp);
+    BHR_HIP(hipGetLastError());
+    return bhr_launch_build_mips(ctx);
+}
+
+int32_t bhr_launch_fill(bhr_ctx *ctx, float *dst, int64_t n, float v) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dst, (long long)n, v);
+    BHR_HIP(hipGetLastError());
+    return BHR_OK;
+}
+
+int32_t bhr_launch_noise(bhr_ctx *ctx, int64_t n, int32_t mode, int32_t octaves, float pers, float lac) {
+    int blocks = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(noise_eval_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->d_noise_in, ctx->d_noise_out,
+                       (long long)n, mode, octaves, pers, lac);
+    BHR_HIP(hipGetLastError());
+    return BHR_OK;
+}

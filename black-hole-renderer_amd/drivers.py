@@ -1,0 +1,227 @@
+"""Frame drivers on top of HipRenderer: single image and video (render.py:4031-4153, 4356-4511).
+
+Kept from the reference: the lifecycle call sequence, the orbit camera, the resume format
+(``.frames_<md5(output)[:16]>/progress.json`` = {params, completed}), PNG frames written by a
+2-thread pool, MP4 assembly through imageio/pyav when those packages exist.
+New: frames can be sharded round-robin over ranks (``rank``/``world``): every rank replays the
+cheap CPU lifecycle for every frame index and renders only its own frames; normalisation
+statistics are recomputed at every ``frame % 60 == 0`` by *frame index* (so the output does not
+depend on the sharding), which also makes a resumed video identical to an uninterrupted one.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import shutil
+import time
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Optional
+
+import numpy as np
+
+from .camera import orbit_position
+from .lifecycle import make_factories
+from .renderer import HipRenderer, R_DISK_INNER_DEFAULT, R_DISK_OUTER_DEFAULT
+from .skybox import load_or_generate_skybox
+from .textures import compute_disk_texture_resolution, load_disk_texture
+
+
+def save_image(image: np.ndarray, path: str) -> None:
+    """float image -> 8-bit PNG with truncation, not rounding (render.py:420-425)."""
+    from PIL import Image
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    Image.fromarray((np.clip(image, 0, 1) * 255).astype(np.uint8), "RGB").save(path)
+    print(f"Saved: {path}")
+
+
+def init_lifecycle_system(renderer: HipRenderer, n_r: int, n_phi: int, seed: int = 42) -> dict:
+    """Background parameters + the three pre-aged entity populations + a first composed texture
+    (render.py:4079-4130)."""
+    renderer.init_background_layer(n_r=n_r, n_phi=n_phi, seed=seed)
+    factories = make_factories(n_r, n_phi, renderer.r_disk_inner, renderer.r_disk_outer, seed=seed)
+    renderer.generate_background(t=0.0)
+    renderer.accumulate_entity_layer(factories, now=0.0)
+    renderer.recompute_interactive_stats()
+    renderer.compose_interactive_texture()
+    return factories
+
+
+def advance_lifecycle_frame(renderer: HipRenderer, factories: dict, t: float, dt: float,
+                            recompute_stats: bool = False, solo_idx: int = -1, compose: bool = True) -> None:
+    """Tick the factories and rebuild the texture for time t (render.py:4133-4153).
+    ``compose=False`` only advances the CPU state (used by ranks skipping a frame they do not render)."""
+    for f in factories.values():
+        f.tick(now=t, dt=dt)
+    if not compose and not recompute_stats:
+        return
+    renderer.generate_background(t=t)
+    renderer.accumulate_entity_layer(factories, now=t)
+    if recompute_stats:
+        renderer.recompute_interactive_stats()
+    if compose:
+        renderer.compose_interactive_texture(solo_idx=solo_idx)
+
+
+def make_renderer(width, height, cam_pos, fov, step_size=0.1, skybox_path=None, n_stars=6000, tex_w=2048,
+                  tex_h=1024, r_max=10.0, disk_texture_path=None, r_disk_inner=R_DISK_INNER_DEFAULT,
+                  r_disk_outer=R_DISK_OUTER_DEFAULT, disk_tilt=0.0, lens_flare=False, anti_alias="disabled",
+                  aa_strength=1.0, disk_rotation_speed=0.1, device_index=0, rows=None):
+    """Renderer with a placeholder (or file) disk texture, as the reference's entry points build it
+    (render.py:4044-4064, 4627-4644).  Returns (renderer, use_lifecycle, n_r, n_phi)."""
+    skybox, tex_h, tex_w = load_or_generate_skybox(skybox_path, tex_w, tex_h, n_stars)
+    disk_tex = load_disk_texture(disk_texture_path)
+    use_lifecycle = disk_tex is None
+    if use_lifecycle:
+        n_phi, n_r = compute_disk_texture_resolution(width, height, cam_pos, fov, r_disk_inner, r_disk_outer)
+        disk_tex = np.zeros((n_r, n_phi, 4), dtype=np.float32)
+    else:
+        n_r, n_phi = disk_tex.shape[:2]
+    renderer = HipRenderer(width, height, skybox, disk_tex, step_size=step_size, r_max=r_max,
+                           r_disk_inner=r_disk_inner, r_disk_outer=r_disk_outer, disk_tilt=disk_tilt,
+                           lens_flare=lens_flare, anti_alias=anti_alias, aa_strength=aa_strength,
+                           disk_rotation_speed=disk_rotation_speed, device_index=device_index, rows=rows)
+    return renderer, use_lifecycle, n_r, n_phi
+
+
+def render_image(width: int, height: int, cam_pos: List[float], fov: float, step_size: float,
+                 skybox_path: Optional[str] = None, n_stars: int = 6000, tex_w: int = 2048, tex_h: int = 1024,
+                 r_max: float = 10.0, device: str = "hip", disk_texture_path: Optional[str] = None,
+                 r_disk_inner: float = R_DISK_INNER_DEFAULT, r_disk_outer: float = R_DISK_OUTER_DEFAULT,
+                 disk_tilt: float = 0.0, lens_flare: bool = False, anti_alias: str = "disabled",
+                 aa_strength: float = 1.0, disk_rotation_speed: float = 0.1, disk_generation_scale: int = 2,
+                 force_regenerate_disk_texture: bool = False, ignore_taichi_cache: bool = False,
+                 gpus: int = 1) -> np.ndarray:
+    """One frame -> (H, W, 3) float32 (render.py:4031-4076).  ``gpus > 1`` tiles the frame in row
+    blocks over that many devices of this node (bhr_group_render)."""
+    if gpus > 1:
+        from .multigpu import render_image_tiled
+        return render_image_tiled(width, height, cam_pos, fov, gpus, step_size=step_size, skybox_path=skybox_path,
+                                  n_stars=n_stars, tex_w=tex_w, tex_h=tex_h, r_max=r_max,
+                                  disk_texture_path=disk_texture_path, r_disk_inner=r_disk_inner,
+                                  r_disk_outer=r_disk_outer, disk_tilt=disk_tilt, lens_flare=lens_flare,
+                                  anti_alias=anti_alias, aa_strength=aa_strength,
+                                  disk_rotation_speed=disk_rotation_speed)
+    renderer, use_lifecycle, n_r, n_phi = make_renderer(
+        width, height, cam_pos, fov, step_size, skybox_path, n_stars, tex_w, tex_h, r_max, disk_texture_path,
+        r_disk_inner, r_disk_outer, disk_tilt, lens_flare, anti_alias, aa_strength, disk_rotation_speed)
+    if use_lifecycle:
+        factories = init_lifecycle_system(renderer, n_r, n_phi, seed=42)
+        advance_lifecycle_frame(renderer, factories, t=0.0, dt=0.0, recompute_stats=True)
+    t0 = time.time()
+    print(f"HIP: {width}x{height}, cam_pos={list(cam_pos)}, fov={fov}°, step_size={step_size}")
+    img = renderer.render(cam_pos, fov, frame=0)
+    c = renderer.counters()
+    dt = time.time() - t0
+    print(f"Done in {dt:.3f}s  (march {c['march_ms']:.2f} ms, bloom {c['bloom_ms']:.2f} ms, "
+          f"{c['ray_steps'] / 1e6:.1f} Mray-steps, {c['ray_steps'] / max(c['march_ms'], 1e-6) / 1e3:.0f} Mray-steps/s)")
+    renderer.close()
+    return img
+
+
+def _frames_dir(output_path: str) -> str:
+    name = ".frames_" + hashlib.md5(output_path.encode()).hexdigest()[:16]
+    return os.path.join(os.path.dirname(output_path), name)
+
+
+def assemble_video(temp_dir: str, n_frames: int, fps: int, output_path: str) -> bool:
+    """PNG frames -> libx264 MP4 through imageio's pyav plugin (render.py:4497-4503).  Returns False
+    (frames are kept) when imageio / av are not installed."""
+    try:
+        import imageio.v3 as iio
+        import av  # noqa: F401
+    except ImportError:
+        print(f"imageio/pyav not available: frames kept in {temp_dir}; encode with\n"
+              f"  ffmpeg -framerate {fps} -i {temp_dir}/frame_%04d.png -c:v libx264 -crf 18 -pix_fmt yuv420p {output_path}")
+        return False
+    writer = iio.imopen(output_path, "w", plugin="pyav")
+    writer.init_video_stream("libx264", fps=fps)
+    for frame in range(n_frames):
+        writer.write_frame(iio.imread(os.path.join(temp_dir, f"frame_{frame:04d}.png")))
+    writer.close()
+    print(f"Video saved: {output_path}")
+    return True
+
+
+def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, fps: int, output_path: str,
+                 fov: float, static_cam_pos: List[float], orbit: bool = False, resume: bool = False,
+                 disk_rotation_speed: float = 0.1, orbit_degrees: float = 360.0, rank: int = 0, world: int = 1,
+                 assemble: bool = True, **_deprecated_kwargs) -> None:
+    """N frames -> PNGs (+ MP4) (render.py:4356-4511).  Frame f is rendered by rank f % world."""
+    from PIL import Image
+    os.makedirs(os.path.dirname(output_path) or ".", exist_ok=True)
+    temp_dir = _frames_dir(output_path)
+    progress_file = os.path.join(temp_dir, f"progress.json" if world == 1 else f"progress.rank{rank}.json")
+    params = {"n_frames": n_frames, "fov": fov, "orbit": orbit, "disk_rotation_speed": disk_rotation_speed,
+              "orbit_degrees": orbit_degrees}
+
+    completed = set()
+    if resume and os.path.isdir(temp_dir) and os.path.isfile(progress_file):
+        with open(progress_file) as f:
+            saved = json.load(f)
+        if saved.get("params", {}) != params:
+            print("Warning: parameters changed, starting over")
+            if rank == 0:
+                shutil.rmtree(temp_dir)
+            os.makedirs(temp_dir, exist_ok=True)
+        else:
+            completed = set(saved.get("completed", []))
+            print(f"Resuming: {len(completed)}/{n_frames} frames already rendered")
+    else:
+        os.makedirs(temp_dir, exist_ok=True)
+
+    total_t0 = time.time()
+    rendered = 0
+    pool = ThreadPoolExecutor(max_workers=2)
+    pending = []
+
+    def _save_png(path, img_u8):
+        Image.fromarray(img_u8, "RGB").save(path)
+
+    n_r, n_phi = renderer.dtex_h, renderer.dtex_w
+    factories = init_lifecycle_system(renderer, n_r, n_phi, seed=42)
+    dt = disk_rotation_speed
+    print(f"  lifecycle system ready (n_r={n_r}, n_phi={n_phi}), rank {rank}/{world}")
+
+    for frame in range(n_frames):
+        t = frame * dt
+        mine = frame % world == rank and frame not in completed
+        # the factories advance on every frame index on every rank; statistics are a function of the
+        # frame index (every 60th), texture composition only happens for frames rendered here
+        advance_lifecycle_frame(renderer, factories, t, dt, recompute_stats=(frame % 60 == 0), compose=mine)
+        if not mine:
+            continue
+        cam_pos = orbit_position(static_cam_pos, frame, n_frames, orbit_degrees) if orbit else static_cam_pos
+        t0 = time.time()
+        if renderer.lens_flare:
+            img = renderer.render(cam_pos, fov, frame=0)
+            img_u8 = (np.clip(img, 0, 1) * 255).astype(np.uint8)
+        else:
+            renderer.render_async(cam_pos, fov, frame=0)
+            img_u8 = renderer.read_final_u8()      # quantised on the device
+        elapsed = time.time() - t0
+        rendered += 1
+        if len(pending) >= 4:
+            pending.pop(0).result()
+        pending.append(pool.submit(_save_png, os.path.join(temp_dir, f"frame_{frame:04d}.png"), img_u8))
+        completed.add(frame)
+        if rendered % 10 == 0 or frame >= n_frames - world:
+            with open(progress_file, "w") as f:
+                json.dump({"params": params, "completed": sorted(completed)}, f)
+        if rendered % 100 == 0 or frame == n_frames - 1:
+            print(f"  frame {frame}/{n_frames} {elapsed * 1e3:.1f} ms, done {len(completed)}")
+
+    for f in pending:
+        f.result()
+    pool.shutdown(wait=False)
+    with open(progress_file, "w") as f:
+        json.dump({"params": params, "completed": sorted(completed)}, f)
+    if rendered:
+        print(f"Session rendered {rendered} frames in {time.time() - total_t0:.1f} s "
+              f"({rendered / (time.time() - total_t0):.1f} fps incl. PNG encode)")
+    if world > 1 or not assemble:
+        return       # rank 0 assembles after a barrier (cli.py)
+    if len(completed) < n_frames:
+        print(f"Warning: only {len(completed)}/{n_frames} frames completed. Run again to resume.")
+        return
+    assemble_video(temp_dir, n_frames, fps, output_path)

@@ -1,0 +1,30 @@
+"""Scene set-up for bench.py / profiling: the BASELINE.json workloads with all inputs resident in HBM."""
+from __future__ import annotations
+
+import numpy as np
+
+from .renderer import HipRenderer
+from .textures import compute_disk_texture_resolution
+
+
+def make_scene(wl: dict, device_index: int = 0, n_stars: int = 6000, procedural: bool = True):
+    """Renderer for workload ``wl`` (see bench.WORKLOADS) with the reference's default scene:
+    procedural skybox (generate_skybox(2048, 1024, seed 42)) and the lifecycle disk texture at
+    t = 0 (render_image, render.py:4044-4069).  Returns (renderer, skybox, disk_tex, note)."""
+    from .skybox import generate_skybox
+    from .drivers import init_lifecycle_system, advance_lifecycle_frame
+
+    W, H = wl["width"], wl["height"]
+    r_in, r_out = 2.0, 15.0
+    n_phi, n_r = compute_disk_texture_resolution(W, H, wl["cam_pos"], wl["fov"], r_in, r_out)
+    sky = generate_skybox(2048, 1024, seed=42, n_stars=n_stars)
+    placeholder = np.zeros((n_r, n_phi, 4), dtype=np.float32)
+    r = HipRenderer(W, H, sky, placeholder, step_size=wl["step_size"], r_max=10.0, r_disk_inner=r_in,
+                    r_disk_outer=r_out, disk_tilt=wl["disk_tilt"], anti_alias=wl["anti_alias"],
+                    device_index=device_index)
+    factories = init_lifecycle_system(r, n_r, n_phi, seed=42)
+    advance_lifecycle_frame(r, factories, t=0.0, dt=0.0, recompute_stats=True)
+    tex = r.disk_texture_field.to_numpy()
+    note = (f"procedural skybox 1024x2048 seed 42 ({n_stars} stars) + lifecycle disk texture "
+            f"{n_r}x{n_phi} seed 42 at t=0, generated on the device")
+    return r, sky, tex, note

@@ -1,0 +1,188 @@
+/*
+ * bhr.h -- C ABI of libbhr_hip.so, the MI355X (gfx950) Schwarzschild ray tracer.
+ *
+ * The reference (hwuu/black-hole-renderer) has no FFI: its renderer boundary is
+ * the Python class TaichiRenderer (render.py:2189-4028) whose device half is
+ * JIT-compiled Taichi.  This header is the boundary a maintainer would bind in
+ * its place; each entry point names the reference interface it replaces.  The
+ * ctypes binding that mirrors TaichiRenderer lives in
+ * black-hole-renderer_amd/renderer.py; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - every call returns 0 on success or a negative bhr_status; bhr_last_error()
+ *    returns a thread-local message for the last failure on the calling thread;
+ *  - a bhr_ctx owns one HIP device, one stream and all its device buffers.  It
+ *    is not thread-safe; distinct contexts may be driven from distinct threads
+ *    or processes (one process per GPU, or one process driving N devices);
+ *  - host pointers are plain row-major float32 arrays owned by the caller and
+ *    copied during the call; nothing in this ABI is a torch/Taichi type;
+ *  - images handed back to the host are (rows, width, 3) float32, x fastest,
+ *    i.e. already in the (H, W, 3) order TaichiRenderer.render() returns after
+ *    its final transpose (render.py:3923);
+ *  - the library never falls back to a CPU path: without a HIP device
+ *    bhr_create() fails with BHR_ERR_NO_DEVICE.
+ */
+#ifndef BHR_H
+#define BHR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BHR_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define BHR_API __attribute__((visibility("default")))
+#else
+#define BHR_API
+#endif
+
+typedef struct bhr_ctx bhr_ctx;
+
+typedef enum {
+    BHR_OK = 0,
+    BHR_ERR_INVALID = -1,      /* bad argument / shape mismatch (reference: AssertionError, ValueError) */
+    BHR_ERR_NO_DEVICE = -2,    /* no usable HIP device */
+    BHR_ERR_HIP = -3,          /* a HIP runtime call failed; see bhr_last_error() */
+    BHR_ERR_STATE = -4,        /* call sequence violated (e.g. background before bhr_bg_init) */
+    BHR_ERR_NOMEM = -5
+} bhr_status;
+
+/* Constructor arguments of TaichiRenderer.__init__ (render.py:2199-2208), plus
+ * the device ordinal and the row block [row0,row1) of the image this context
+ * renders (0,height for a whole frame; row blocks are the multi-GPU tiles). */
+typedef struct {
+    int32_t width, height;
+    int32_t row0, row1;
+    float step_size;            /* h_base                   (default 0.1)  */
+    float r_max;                /* escape radius floor      (default 10)   */
+    float r_disk_inner;         /* default 2.0  */
+    float r_disk_outer;         /* default 15.0 */
+    float disk_tilt_deg;        /* default 0    */
+    int32_t anti_alias;         /* 0 = "disabled", 1 = "lod_radius"        */
+    float aa_strength;          /* default 1.0  */
+    float disk_rotation_speed;  /* t_offset = frame * this (render.py:3897) */
+    int32_t device;             /* HIP device ordinal */
+} bhr_config;
+
+/* Camera uniforms exactly as TaichiRenderer.render() uploads them
+ * (render.py:3880-3892): build_camera() in f64 on the host, cast to f32. */
+typedef struct {
+    float pos[3], right[3], up[3], forward[3];
+    float pixel_width, pixel_height;
+    float r_escape;             /* max(r_max, 2*|cam_pos|)  (render.py:3884) */
+    float t_offset;             /* frame * disk_rotation_speed */
+} bhr_camera;
+
+/* bhr_render flags */
+#define BHR_SKIP_DIFFERENTIALS 1u  /* render(skip_differentials=True): plain bilinear disk lookup */
+#define BHR_SKIP_BLOOM         2u  /* render(skip_bloom=True) */
+#define BHR_NO_COMPACTION      4u  /* debugging: tile kernel without wave refill */
+
+/* selectors for bhr_read_layer */
+typedef enum {
+    BHR_LAYER_FINAL = 0,  /* clip(bg + disk + blur, 0, 1)           render.py:3918 */
+    BHR_LAYER_BG = 1,     /* image_field  = skybox * (1 - alpha)    render.py:3017 */
+    BHR_LAYER_DISK = 2,   /* disk_layer_field = clamp(accum, 0, 1)  render.py:3018 */
+    BHR_LAYER_BLUR = 3    /* blur_field after the V pass            render.py:3108 */
+} bhr_layer;
+
+typedef struct {
+    uint64_t ray_steps;      /* executed while-loop iterations of the last march (render.py:2854) */
+    uint64_t rays;           /* pixels marched by the last bhr_render */
+    float march_ms;          /* HIP-event time of the march kernel, on the ctx stream */
+    float bloom_ms;          /* H pass + V pass + combine */
+    float frame_ms;          /* first launch .. last launch of bhr_render */
+    float background_ms;     /* last bhr_generate_background */
+    float compose_ms;        /* last bhr_compose_texture (compose + mip chain) */
+    int32_t march_vgprs;     /* registers per lane of the march kernel that ran (hipFuncGetAttributes) */
+    int32_t march_lds_bytes;
+    /* sums over the bhr_render calls since bhr_timing_reset (at most the last
+     * BHR_TIMING_RING calls), each launch bracketed by its own HIP events on the ctx stream */
+    int32_t frames_timed;
+    float march_ms_sum;
+    float bloom_ms_sum;
+    uint64_t ray_steps_sum;  /* ray_steps of one frame x frames_timed is NOT assumed: summed per frame */
+} bhr_counters;
+
+#define BHR_TIMING_RING 512
+
+BHR_API const char *bhr_last_error(void);
+BHR_API int32_t bhr_abi_version(void);
+BHR_API int32_t bhr_device_count(void);
+
+/* ---- lifetime: TaichiRenderer.__init__ / garbage collection -------------- */
+BHR_API int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out);
+BHR_API void bhr_destroy(bhr_ctx *ctx);
+BHR_API int32_t bhr_sync(bhr_ctx *ctx);
+
+/* ---- scene data ----------------------------------------------------------- */
+/* texture_field.from_numpy(skybox): (tex_h, tex_w, 3) f32   render.py:2232-2233 */
+BHR_API int32_t bhr_set_skybox(bhr_ctx *ctx, const float *rgb, int32_t tex_h, int32_t tex_w);
+/* disk_texture_field.from_numpy + generate_disk_mipmaps(levels=4) + padded
+ * upload (render.py:2235-2251, update_disk_texture 2292-2312).  (n_r, n_phi, 4)
+ * f32.  The first call fixes (n_r, n_phi); later calls must match
+ * (reference: AssertionError at render.py:2299 -> BHR_ERR_INVALID).  The mip
+ * chain is built on the device and stored packed (1.33x, not 5x). */
+BHR_API int32_t bhr_set_disk_texture(bhr_ctx *ctx, const float *rgba, int32_t n_r, int32_t n_phi);
+/* disk_texture_field.to_numpy() */
+BHR_API int32_t bhr_get_disk_texture(bhr_ctx *ctx, float *rgba_out);
+/* disk_mips_field.to_numpy(): level `level` only, (n_r>>level, n_phi>>level, 4) */
+BHR_API int32_t bhr_get_disk_mip(bhr_ctx *ctx, int32_t level, float *rgba_out);
+BHR_API int32_t bhr_num_mip_levels(bhr_ctx *ctx);
+
+/* ---- procedural disk-texture pipeline ------------------------------------- */
+/* init_background_layer (render.py:3491-3547): allocates comp (13,n_r,n_phi),
+ * uploads edge[n_r], omega_rows[n_r], initial stats; az_freq/az_shear are the
+ * two RNG draws the host makes. */
+BHR_API int32_t bhr_bg_init(bhr_ctx *ctx, int32_t n_r, int32_t n_phi, int32_t az_freq, float az_shear,
+                    const float *edge, const float *omega_rows);
+/* generate_background(t) -> _generate_background_kernel  (render.py:3549-3562, 3332-3451) */
+BHR_API int32_t bhr_generate_background(bhr_ctx *ctx, float t);
+/* accumulate_entity_layer's upload half: staging (6,n_r,n_phi) -> comp[5..10]
+ * (render.py:3651-3653, 3455-3471) */
+BHR_API int32_t bhr_set_entity_staging(bhr_ctx *ctx, const float *staging);
+/* upload_parametric_state's comp upload: all 13 planes (render.py:2336-2353) */
+BHR_API int32_t bhr_set_comp(bhr_ctx *ctx, const float *comp13);
+/* _comp_field.to_numpy() (render.py:3666) */
+BHR_API int32_t bhr_read_comp(bhr_ctx *ctx, float *comp13_out);
+/* _zero_comp_slice / _fill_comp_slice (render.py:3475-3487) */
+BHR_API int32_t bhr_fill_comp_slice(bhr_ctx *ctx, int32_t idx, float value);
+/* _param_stats_field / _param_row_stats_field uploads (render.py:3708-3712):
+ * stats = {density_p98, struct_scale}; row_stats (n_r, 2) = {max, p70} */
+BHR_API int32_t bhr_set_compose_stats(bhr_ctx *ctx, float density_p98, float struct_scale, const float *row_stats);
+/* _compose_disk_texture_kernel + mip chain (render.py:3755-3767, 3805-3817) */
+BHR_API int32_t bhr_compose_texture(bhr_ctx *ctx, float t_offset, int32_t enable_rt, float color_temp);
+/* eval_noise (render.py:3769-3790): coords (n,3); mode 0 simplex, 1 fbm */
+BHR_API int32_t bhr_eval_noise(bhr_ctx *ctx, const float *coords, int64_t n, int32_t mode, int32_t octaves,
+                       float persistence, float lacunarity, float *out);
+
+/* ---- the hot path: TaichiRenderer.render() (render.py:3865-3923) ----------
+ * Launches the fused ray-march kernel for rows [row0,row1), then (unless
+ * BHR_SKIP_BLOOM) the bloom H pass, V pass and final combine.  Asynchronous on
+ * the context's stream; results stay in HBM until read. */
+BHR_API int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);
+/* image_field/disk_layer_field/blur_field .to_numpy() and the final image,
+ * for the context's rows: (row1-row0, width, 3) f32.  Synchronises. */
+BHR_API int32_t bhr_read_layer(bhr_ctx *ctx, int32_t layer, float *out);
+/* save_image()'s quantisation (clip*255 truncated to u8, render.py:423) done
+ * on the device: (row1-row0, width, 3) u8.  Synchronises. */
+BHR_API int32_t bhr_read_final_u8(bhr_ctx *ctx, uint8_t *out);
+BHR_API int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out);
+/* forget the per-frame timing ring (call before a timed region) */
+BHR_API int32_t bhr_timing_reset(bhr_ctx *ctx);
+
+/* ---- multi-GPU row-block tiling (one process driving N devices) -----------
+ * ctxs[k] renders rows [row0_k,row1_k) of the same image; blocks must be
+ * contiguous, ordered and cover [0,height).  Marches all tiles concurrently,
+ * exchanges the R = int(0.02*W) H-blurred halo rows between neighbours with
+ * hipMemcpyPeerAsync, runs the V pass per tile and gathers the final tiles
+ * into ctxs[0] (device) and, if out_host != NULL, into out_host (H, W, 3). */
+BHR_API int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHR_H */

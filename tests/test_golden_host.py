@@ -1,0 +1,129 @@
+"""Host-side helpers of the product against vectors captured from the reference's own NumPy code
+(tests/golden/make_golden.py).  CPU only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def g(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_camera_matches_reference_bitwise(oracle):
+    from bhr_amd.camera import build_camera
+    d = g("camera.npz")
+    for row, want in zip(d["inputs"], d["outputs"]):
+        pos, fov, w, h = list(row[:3]), row[3], int(row[4]), int(row[5])
+        for impl in (build_camera, oracle.build_camera):
+            p, r, u, f, pw, ph = impl(pos, fov, w, h)
+            got = np.concatenate([p, r, u, f, [pw, ph]])
+            np.testing.assert_array_equal(got, want)
+
+
+def test_orbit_positions():
+    from bhr_amd.camera import orbit_position
+    for n_frames, deg, fr, x, y, z in g("orbit.npz")["rows"]:
+        got = orbit_position([6.0, 0.0, 0.5], int(fr), int(n_frames), float(deg))
+        np.testing.assert_array_equal(np.array(got), np.array([x, y, z]))
+
+
+def test_texture_resolution_edge_alpha_mips_blackbody():
+    from bhr_amd import textures
+    from bhr_amd.skybox import blackbody_rgb
+    d = g("texture_helpers.npz")
+    for row, want in zip(d["res_in"], d["res_out"]):
+        w, h, px, py, pz, fov, r_in, r_out = row
+        got = textures.compute_disk_texture_resolution(int(w), int(h), [px, py, pz], fov, r_in, r_out)
+        assert tuple(got) == tuple(int(v) for v in want)
+    np.testing.assert_array_equal(textures.compute_edge_alpha(128), d["edge_128"])
+    np.testing.assert_array_equal(textures.compute_edge_alpha(17), d["edge_17"])
+    mips = textures.generate_disk_mipmaps(d["mip_base"], levels=4)
+    assert len(mips) == 5
+    for i, m in enumerate(mips):
+        np.testing.assert_array_equal(m, d[f"mip_{i}"])
+    np.testing.assert_array_equal(blackbody_rgb(d["bb_T"]), d["bb_rgb"])
+
+
+def test_texture_resolution_baseline_sizes():
+    """e2e (128,336), fhd (416,2912), 4k (832,5824), 8k (1648,11632) as (n_r, n_phi)."""
+    from bhr_amd.textures import compute_disk_texture_resolution as res
+    assert res(320, 180, [6, 0, 0.5], 60, 2.0, 3.5) == (336, 128)
+    assert res(1920, 1080, [6, 0, 0.5], 90, 2.0, 15.0) == (2912, 416)
+    assert res(3840, 2160, [6, 0, 0.5], 90, 2.0, 15.0) == (5824, 832)
+    assert res(7680, 4320, [6, 0, 0.5], 90, 2.0, 15.0) == (11632, 1648)
+
+
+def test_skybox_small_and_full_size():
+    from bhr_amd.skybox import generate_skybox
+    d = g("skybox.npz")
+    np.testing.assert_array_equal(generate_skybox(64, 32, seed=42, n_stars=10), d["small"])
+    big = generate_skybox(2048, 1024, seed=42, n_stars=6000)
+    assert str(big.dtype) == str(d["big_dtype"])
+    np.testing.assert_array_equal(big[d["big_ys"], d["big_xs"]], d["big_samples"])
+    assert hashlib.sha256(big.tobytes()).hexdigest() == str(d["big_sha256"])
+
+
+def _factories(n_r, n_phi, r_in, r_out):
+    from bhr_amd.lifecycle import make_factories
+    return make_factories(n_r, n_phi, r_in, r_out, seed=42)
+
+
+def test_lifecycle_population_and_rasterisation():
+    from bhr_amd.lifecycle import rasterize_entities
+    from bhr_amd.textures import keplerian_omega_rows
+    d = g("lifecycle.npz")
+    n_r, n_phi, r_in, r_out = int(d["n_r"]), int(d["n_phi"]), float(d["r_inner"]), float(d["r_outer"])
+    fac = _factories(n_r, n_phi, r_in, r_out)
+    omega = keplerian_omega_rows(n_r, r_in, r_out)
+    r_norm = np.linspace(0, 1, n_r)
+
+    def check(tag, now):
+        for k, f in fac.items():
+            np.testing.assert_array_equal(np.array([e.birth_time for e in f.entities]), d[f"birth_{k}_{tag}"])
+            np.testing.assert_array_equal(np.array([e.lifetime for e in f.entities]), d[f"lifetime_{k}_{tag}"])
+            np.testing.assert_array_equal(np.array([e.omega for e in f.entities]), d[f"omega_{k}_{tag}"])
+            np.testing.assert_array_equal(np.array([len(e.row_indices) for e in f.entities]), d[f"nrows_{k}_{tag}"])
+            np.testing.assert_array_equal(np.array([float(e.fade_noise.sum()) for e in f.entities]),
+                                          d[f"fade_noise_sum_{k}_{tag}"])
+        np.testing.assert_array_equal(rasterize_entities(fac, now, n_r, n_phi, omega, r_norm), d[f"staging_{tag}"])
+
+    check("t0", 0.0)
+    for fr in range(1, 121):
+        for f in fac.values():
+            f.tick(now=fr * 0.1, dt=0.1)
+    check("t12", 12.0)
+    for fr in range(121, 1201):
+        for f in fac.values():
+            f.tick(now=fr * 0.1, dt=0.1)
+    check("t120", 120.0)
+
+
+def test_compose_statistics():
+    from bhr_amd.lifecycle import compose_statistics
+    from bhr_amd.textures import compute_edge_alpha
+    d = g("lifecycle.npz")
+    p98, scale, rows = compose_statistics(d["stats_comp"], compute_edge_alpha(int(d["n_r"])), 1)
+    np.testing.assert_array_equal(np.array([p98, scale], dtype=np.float32), d["stats_out"])
+    np.testing.assert_array_equal(rows, d["row_stats_out"])
+
+
+def test_background_rng_draws():
+    for seed, az_freq, az_shear in g("misc.npz")["az_draws"]:
+        rng = np.random.default_rng(int(seed))
+        assert int(rng.integers(2, 5)) == int(az_freq)
+        assert float(rng.uniform(2.0, 4.0)) == float(az_shear)
+
+
+def test_lens_flare():
+    from bhr_amd.flare import apply_lens_flare
+    d = g("misc.npz")
+    final = np.ascontiguousarray(d["flare_final"].transpose(1, 0, 2))   # reference arrays are (W, H, 3)
+    disk = np.ascontiguousarray(d["flare_disk"].transpose(1, 0, 2))
+    out = apply_lens_flare(final, disk)
+    np.testing.assert_array_equal(out.transpose(1, 0, 2), d["flare_out"])
+    dark = apply_lens_flare(final, np.zeros_like(disk))                  # early-out: no disk light
+    np.testing.assert_array_equal(dark.transpose(1, 0, 2), d["flare_dark_out"])
