@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--workload", default="fhd", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-kernel", action="store_true", help="A/B: tile schedule instead of persistent refill")
+    ap.add_argument("--math", default=None, choices=["fast", "strict"], help="march arithmetic (default: the renderer's)")
     return ap.parse_args()
 
 
@@ -97,7 +98,7 @@ def main():
 
     from bhr_amd import workloads
     wl = WORKLOADS[args.workload]
-    renderer, sky, tex, scene_note = workloads.make_scene(wl, device_index=local_rank)
+    renderer, sky, tex, scene_note = workloads.make_scene(wl, device_index=local_rank, math=args.math)
 
     def barrier():
         if dist is not None:
@@ -155,6 +156,7 @@ def main():
                        "scene": scene_note, "frames_per_rank": args.steps,
                        "sharding": "independent frames per rank, no collective",
                        "march_schedule": "tile" if args.tile_kernel else "persistent+refill",
+                       "march_math": renderer.math,
                        "ray_steps_per_frame": int(steps_per_frame), "steps_per_ray": steps_per_frame / pixels},
             "kernel_ms": {"march": march_ms, "bloom_and_combine": bloom_ms, "frames_timed": n_frames,
                           "march_vgprs": c["march_vgprs"]},

@@ -13,7 +13,8 @@ from .build import library_path
 BHR_OK = 0
 BHR_ERR_INVALID, BHR_ERR_NO_DEVICE, BHR_ERR_HIP, BHR_ERR_STATE, BHR_ERR_NOMEM = -1, -2, -3, -4, -5
 
-SKIP_DIFFERENTIALS, SKIP_BLOOM, NO_COMPACTION = 1, 2, 4
+SKIP_DIFFERENTIALS, SKIP_BLOOM, PERSISTENT = 1, 2, 4
+MATH_FAST, MATH_STRICT = 0, 1
 LAYER_FINAL, LAYER_BG, LAYER_DISK, LAYER_BLUR = 0, 1, 2, 3
 
 # every symbol include/bhr.h declares (tests check the .so exports exactly these)
@@ -30,7 +31,8 @@ class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("row0", C.c_int32), ("row1", C.c_int32),
                 ("step_size", C.c_float), ("r_max", C.c_float), ("r_disk_inner", C.c_float),
                 ("r_disk_outer", C.c_float), ("disk_tilt_deg", C.c_float), ("anti_alias", C.c_int32),
-                ("aa_strength", C.c_float), ("disk_rotation_speed", C.c_float), ("device", C.c_int32)]
+                ("aa_strength", C.c_float), ("disk_rotation_speed", C.c_float), ("device", C.c_int32),
+                ("math_mode", C.c_int32)]
 
 
 class Camera(C.Structure):

@@ -8,7 +8,8 @@ LIB_DIR = os.path.join(_HERE, "lib")
 
 
 def library_path() -> str:
-    return os.path.join(LIB_DIR, "libbhr_hip.so")
+    """In-tree library; BHR_HIP_LIBRARY selects another build of the same ABI (A/B experiments)."""
+    return os.environ.get("BHR_HIP_LIBRARY") or os.path.join(LIB_DIR, "libbhr_hip.so")
 
 
 def sources():

@@ -37,7 +37,8 @@ struct BhrScene {
 // Kernel argument block of the march (passed by value -> SGPRs).
 struct BhrMarchArgs {
     float cp[3], cr[3], cu[3], cf[3];
-    float pw, ph, r_esc;
+    float pw, ph, r_esc, r_esc2;
+    float e1[3], r0, A;      // fast build: e1 = cam/|cam|, r0 = |cam|, A = n.e1 with n = (0, -tan_t, 1)
     float h_base, r_inner, r_outer, t_offset;
     float tilt_rad, tan_t, sin_t, cos_t;
     float aa_strength;
@@ -114,14 +115,15 @@ int32_t bhr_fail(int32_t code, const char *fmt, ...);
     } while (0)
 
 // launchers (each lives next to its kernels)
-int32_t bhr_launch_march(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);
+int32_t bhr_launch_march(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);         // dispatches on math_mode
+int32_t bhr_launch_march_strict(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);  // march_strict.o
+int32_t bhr_march_resources_strict(int32_t *vgprs, int32_t *lds, int32_t diff);
 int32_t bhr_bloom_prepare(bhr_ctx *ctx);
 int32_t bhr_launch_bloom_h(bhr_ctx *ctx);
 int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom);
 int32_t bhr_launch_build_mips(bhr_ctx *ctx);
 int32_t bhr_launch_background(bhr_ctx *ctx, float t);
 int32_t bhr_launch_compose(bhr_ctx *ctx, float t_offset, int32_t enable_rt, float color_temp);
-int32_t bhr_launch_copy_staging(bhr_ctx *ctx, const float *d_staging);
 int32_t bhr_launch_fill(bhr_ctx *ctx, float *dst, int64_t n, float v);
 int32_t bhr_launch_noise(bhr_ctx *ctx, int64_t n, int32_t mode, int32_t octaves, float pers, float lac);
 int32_t bhr_march_resources(int32_t *vgprs, int32_t *lds, int32_t diff);

@@ -47,9 +47,16 @@ class HipRenderer:
                  r_disk_inner=R_DISK_INNER_DEFAULT, r_disk_outer=R_DISK_OUTER_DEFAULT,
                  disk_tilt=0.0, lens_flare=False, anti_alias="disabled", aa_strength=1.0,
                  disk_rotation_speed=0.1, ignore_taichi_cache=False,
-                 device_index: int = 0, rows: Optional[Sequence[int]] = None):
+                 device_index: int = 0, rows: Optional[Sequence[int]] = None, math: str = "strict"):
         if device not in ("hip", "gpu"):
             raise ValueError(f"HipRenderer runs on the GPU only (device={device!r}); there is no CPU path")
+        # math="strict" (default): the RK4 loop in the reference's operation order with IEEE sqrt and
+        # divide -- ray paths bit-identical to a strict f32 evaluation of render.py:2854-3006.
+        # math="fast": 2-D orbital-plane state, v_rsq/v_rcp, fast-math (Taichi's fast_math=True
+        # analogue); ~3x faster, deviates from strict by f32 rounding noise only.
+        if math not in ("fast", "strict"):
+            raise ValueError(f"math must be 'fast' or 'strict', got {math!r}")
+        self.math = math
         if anti_alias not in ("disabled", "lod_radius"):
             raise ValueError(f"anti_alias must be 'disabled' or 'lod_radius', got {anti_alias!r}")
         self.width, self.height = int(width), int(height)
@@ -66,7 +73,7 @@ class HipRenderer:
         cfg = _lib.Config(self.width, self.height, self.row0, self.row1, float(step_size), float(r_max),
                           float(r_disk_inner), float(r_disk_outer), float(disk_tilt),
                           0 if anti_alias == "disabled" else 1, float(aa_strength), float(disk_rotation_speed),
-                          self.device_index)
+                          self.device_index, _lib.MATH_STRICT if math == "strict" else _lib.MATH_FAST)
         handle = C.c_void_p()
         _lib.check(self._lib.bhr_create(C.byref(cfg), C.byref(handle)))
         self._ctx = handle
@@ -270,12 +277,12 @@ class HipRenderer:
         return cam
 
     @staticmethod
-    def _flags(skip_differentials: bool, skip_bloom: bool, compaction: bool = True) -> int:
+    def _flags(skip_differentials: bool, skip_bloom: bool, compaction: bool = False) -> int:
         return ((_lib.SKIP_DIFFERENTIALS if skip_differentials else 0) | (_lib.SKIP_BLOOM if skip_bloom else 0)
-                | (0 if compaction else _lib.NO_COMPACTION))
+                | (_lib.PERSISTENT if compaction else 0))
 
     def render_async(self, cam_pos, fov: float, frame: int = 0, skip_differentials: bool = False,
-                     skip_bloom: bool = False, compaction: bool = True) -> None:
+                     skip_bloom: bool = False, compaction: bool = False) -> None:
         """Launch march + bloom + combine; the frame stays in HBM (counterpart of render_to_field,
         render.py:3819-3863, without the GUI flip)."""
         cam = self.camera_uniforms(cam_pos, fov, frame)

@@ -5,6 +5,8 @@ or seeded NumPy noise, so the same inputs exist in the build container and on th
 """
 import numpy as np
 
+from .textures import compute_edge_alpha
+
 
 def analytic_skybox(tex_h=256, tex_w=512):
     """Direction-to-RGB ramp with a few sharp features (so lensing errors show up)."""
@@ -18,19 +20,23 @@ def analytic_skybox(tex_h=256, tex_w=512):
     return np.ascontiguousarray(sky)
 
 
-def analytic_disk(n_r=128, n_phi=512):
-    """rgba = (0.8, 0.6, 0.4, 0.5 + 0.5 sin(16 phi) sin(8 pi v))."""
+def analytic_disk(n_r=128, n_phi=512, edge=True):
+    """rgba = (0.8, 0.6, 0.4, (0.5 + 0.5 sin(16 phi) sin(8 pi v)) * edge_alpha(v)).  Like every disk
+    texture the reference produces (load_disk_texture, the compose kernel) the alpha is softened to
+    zero at both radial edges; ``edge=False`` keeps a hard-edged disk for stress tests."""
     v, phi = np.meshgrid(np.linspace(0, 1, n_r, dtype=np.float32),
                          np.linspace(0, 2 * np.pi, n_phi, endpoint=False, dtype=np.float32), indexing="ij")
     a = 0.5 + 0.5 * np.sin(16 * phi) * np.sin(8 * np.pi * v)
+    if edge:
+        a = a * compute_edge_alpha(n_r)[:, None]
     tex = np.stack([np.full_like(a, 0.8), np.full_like(a, 0.6), np.full_like(a, 0.4), a], axis=-1)
     return np.ascontiguousarray(tex.astype(np.float32))
 
 
-def noisy_disk(n_r=128, n_phi=512, seed=7):
+def noisy_disk(n_r=128, n_phi=512, seed=7, edge=True):
     """Smooth-ish seeded RGBA texture with texel-scale detail (exercises the LOD path)."""
     rng = np.random.default_rng(seed)
-    base = analytic_disk(n_r, n_phi)
+    base = analytic_disk(n_r, n_phi, edge=edge)
     base[..., :3] *= 0.5 + 0.5 * rng.random((n_r, n_phi, 1), dtype=np.float32)
     base[..., 3] = np.clip(base[..., 3] * (0.6 + 0.4 * rng.random((n_r, n_phi), dtype=np.float32)), 0, 1)
     return np.ascontiguousarray(base)

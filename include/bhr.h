@@ -65,7 +65,15 @@ typedef struct {
     float aa_strength;          /* default 1.0  */
     float disk_rotation_speed;  /* t_offset = frame * this (render.py:3897) */
     int32_t device;             /* HIP device ordinal */
+    int32_t math_mode;          /* BHR_MATH_FAST (0) or BHR_MATH_STRICT (1) */
 } bhr_config;
+
+/* math_mode: FAST uses v_rsq/v_rcp/v_sqrt and FMA contraction inside the RK4 loop (the analogue
+ * of Taichi's fast_math=True default).  STRICT evaluates render.py:2854-3006 operation by operation
+ * with IEEE sqrt/divide: ray paths, step counts and hit points are bit-identical to a strict f32
+ * evaluation of the reference, at roughly twice the march time. */
+#define BHR_MATH_FAST 0
+#define BHR_MATH_STRICT 1
 
 /* Camera uniforms exactly as TaichiRenderer.render() uploads them
  * (render.py:3880-3892): build_camera() in f64 on the host, cast to f32. */
@@ -79,7 +87,7 @@ typedef struct {
 /* bhr_render flags */
 #define BHR_SKIP_DIFFERENTIALS 1u  /* render(skip_differentials=True): plain bilinear disk lookup */
 #define BHR_SKIP_BLOOM         2u  /* render(skip_bloom=True) */
-#define BHR_NO_COMPACTION      4u  /* debugging: tile kernel without wave refill */
+#define BHR_PERSISTENT         4u  /* persistent waves + queue refill instead of the tile schedule */
 
 /* selectors for bhr_read_layer */
 typedef enum {

@@ -59,6 +59,27 @@
 
 #define ORACLE_API __attribute__((visibility("default")))
 
+/* Buffers crossing the API are always IEEE binary32.  With -DORACLE_F64 every intermediate of
+ * the SAME statements is evaluated in binary64 (constants keep their f32 values): the "exact"
+ * value of the reference algorithm, against which the rounding noise of any f32 evaluation
+ * order -- this file's strict build, Taichi's fast-math build, the HIP kernels -- is measured. */
+typedef float f32;
+#ifdef ORACLE_F64
+#define float double
+#define sqrtf sqrt
+#define fminf fmin
+#define fmaxf fmax
+#define floorf floor
+#define powf pow
+#define expf exp
+#define logf log
+#define sinf sin
+#define cosf cos
+#define tanf tan
+#define acosf acos
+#define atan2f atan2
+#endif
+
 /* ---- constants: render.py:37-59 ---------------------------------------- */
 #define RS_F 1.0f
 #define G_FACTOR_CAP 1.5f
@@ -70,8 +91,8 @@
 #define DISK_RADIAL_BRIGHTNESS_MIN 0.2f
 #define DISK_RADIAL_BRIGHTNESS_MAX 8.0f
 
-static const float PI_F = (float)3.141592653589793;       /* ti.math.pi -> f32 */
-static const float TWO_PI_F = (float)(2 * 3.141592653589793); /* 2 * ti.math.pi folded in Python */
+static const float PI_F = (f32)3.141592653589793;         /* ti.math.pi -> f32 (also in the f64 build) */
+static const float TWO_PI_F = (f32)(2 * 3.141592653589793); /* 2 * ti.math.pi folded in Python */
 
 typedef struct { float x, y, z; } v3;
 typedef struct { float x, y, z, w; } v4;
@@ -206,9 +227,9 @@ static inline v3 compute_acc_jacobian(v3 pos, v3 d_pos, float L2)
 }
 
 typedef struct {
-    const float *skybox; int32_t tex_h, tex_w;
-    const float *disk_tex; int32_t dtex_h, dtex_w;
-    const float *disk_mips; int32_t num_mip_levels; /* padded (levels, dtex_h, dtex_w, 4) */
+    const f32 *skybox; int32_t tex_h, tex_w;
+    const f32 *disk_tex; int32_t dtex_h, dtex_w;
+    const f32 *disk_mips; int32_t num_mip_levels; /* padded (levels, dtex_h, dtex_w, 4) */
 } scene_t;
 
 /* ---- render.py:2541-2566 ------------------------------------------------ */
@@ -229,10 +250,10 @@ static v3 sample_skybox(const scene_t *s, v3 d)
     int32_t u1_w = pymod(u0 + 1, tex_w);
     int32_t v0_h = imin(imax(v0, 0), tex_h - 1);
     int32_t v1_h = imin(imax(v0 + 1, 0), tex_h - 1);
-    const float *c00 = s->skybox + ((size_t)v0_h * tex_w + u0_w) * 3;
-    const float *c10 = s->skybox + ((size_t)v0_h * tex_w + u1_w) * 3;
-    const float *c01 = s->skybox + ((size_t)v1_h * tex_w + u0_w) * 3;
-    const float *c11 = s->skybox + ((size_t)v1_h * tex_w + u1_w) * 3;
+    const f32 *c00 = s->skybox + ((size_t)v0_h * tex_w + u0_w) * 3;
+    const f32 *c10 = s->skybox + ((size_t)v0_h * tex_w + u1_w) * 3;
+    const f32 *c01 = s->skybox + ((size_t)v1_h * tex_w + u0_w) * 3;
+    const f32 *c11 = s->skybox + ((size_t)v1_h * tex_w + u1_w) * 3;
     float o[3];
     for (int c = 0; c < 3; ++c)
         o[c] = c00[c] * (1 - fu) * (1 - fv) + c10[c] * fu * (1 - fv) + c01[c] * (1 - fu) * fv + c11[c] * fu * fv;
@@ -246,7 +267,7 @@ static inline float wrap_phi(float phi)
     return phi;
 }
 
-static inline v4 bilerp4(const float *c00, const float *c10, const float *c01, const float *c11, float fu, float fv)
+static inline v4 bilerp4(const f32 *c00, const f32 *c10, const f32 *c01, const f32 *c11, float fu, float fv)
 {
     float o[4];
     for (int c = 0; c < 4; ++c)
@@ -275,7 +296,7 @@ static v4 sample_disk(const scene_t *s, float hit_x, float hit_y, float r_inner,
     int32_t u1_w = pymod(u0 + 1, dtex_w);
     int32_t v0_h = imin(imax(v0, 0), dtex_h - 1);
     int32_t v1_h = imin(imax(v0 + 1, 0), dtex_h - 1);
-    const float *t = s->disk_tex;
+    const f32 *t = s->disk_tex;
     return bilerp4(t + ((size_t)v0_h * dtex_w + u0_w) * 4, t + ((size_t)v0_h * dtex_w + u1_w) * 4,
                    t + ((size_t)v1_h * dtex_w + u0_w) * 4, t + ((size_t)v1_h * dtex_w + u1_w) * 4, fu, fv);
 }
@@ -307,7 +328,7 @@ static v4 sample_disk_mip(const scene_t *s, float hit_x, float hit_y, float r_in
     int32_t u1_w = pymod(u0 + 1, wl);
     int32_t v0_h = imin(imax(v0, 0), (int32_t)(tex_h_lod - 1));
     int32_t v1_h = imin(imax(v0 + 1, 0), (int32_t)(tex_h_lod - 1));
-    const float *t = s->disk_mips + (size_t)lod_i * dtex_h * dtex_w * 4;
+    const f32 *t = s->disk_mips + (size_t)lod_i * dtex_h * dtex_w * 4;
     return bilerp4(t + ((size_t)v0_h * dtex_w + u0_w) * 4, t + ((size_t)v0_h * dtex_w + u1_w) * 4,
                    t + ((size_t)v1_h * dtex_w + u0_w) * 4, t + ((size_t)v1_h * dtex_w + u1_w) * 4, fu, fv);
 }
@@ -397,8 +418,8 @@ static float fbm_3d(float x, float y, float z, int32_t octaves, float persistenc
 }
 
 /* ---- _noise_eval_kernel: render.py:3305-3326 ---------------------------- */
-ORACLE_API void oracle_eval_noise(const float *coords, int64_t n, int32_t mode, int32_t octaves,
-                                  float persistence, float lacunarity, float *out)
+ORACLE_API void oracle_eval_noise(const f32 *coords, int64_t n, int32_t mode, int32_t octaves,
+                                  f32 persistence, f32 lacunarity, f32 *out)
 {
     for (int64_t i = 0; i < n; ++i) {
         float cx = coords[i * 3 + 0], cy = coords[i * 3 + 1], cz = coords[i * 3 + 2];
@@ -408,16 +429,16 @@ ORACLE_API void oracle_eval_noise(const float *coords, int64_t n, int32_t mode, 
 
 /* ---- camera uniforms as uploaded at render.py:3886-3892 ----------------- */
 typedef struct {
-    float cam_pos[3], cam_right[3], cam_up[3], cam_forward[3];
-    float pixel_width, pixel_height, r_escape;
+    f32 cam_pos[3], cam_right[3], cam_up[3], cam_forward[3];
+    f32 pixel_width, pixel_height, r_escape;
 } oracle_camera;
 
 typedef struct {
     int32_t width, height;
-    float h_base, r_inner, r_outer, t_offset, disk_tilt;
+    f32 h_base, r_inner, r_outer, t_offset, disk_tilt;
     int32_t skip_diff;        /* kernel argument skip_diff */
     int32_t anti_alias_mode;  /* 0 disabled, 1 lod_radius (compile-time in the reference) */
-    float aa_strength;
+    f32 aa_strength;
 } oracle_march_params;
 
 /* ---- _ray_march_kernel: render.py:2787-3018 ------------------------------
@@ -426,10 +447,10 @@ typedef struct {
  * one (SURVEY 8d definition of a ray-step).  Returns total ray-steps.
  * i_lo..i_hi / j_lo..j_hi restrict the pixel range (for sampling/timing). */
 ORACLE_API int64_t oracle_ray_march(const oracle_camera *cam, const oracle_march_params *p,
-                                    const float *skybox, int32_t tex_h, int32_t tex_w,
-                                    const float *disk_tex, int32_t dtex_h, int32_t dtex_w,
-                                    const float *disk_mips, int32_t num_mip_levels,
-                                    float *image_out, float *disk_out, int32_t *steps_out,
+                                    const f32 *skybox, int32_t tex_h, int32_t tex_w,
+                                    const f32 *disk_tex, int32_t dtex_h, int32_t dtex_w,
+                                    const f32 *disk_mips, int32_t num_mip_levels,
+                                    f32 *image_out, f32 *disk_out, int32_t *steps_out,
                                     int32_t j_lo, int32_t j_hi)
 {
     scene_t sc = {skybox, tex_h, tex_w, disk_tex, dtex_h, dtex_w, disk_mips, num_mip_levels};
@@ -639,8 +660,8 @@ ORACLE_API int64_t oracle_ray_march(const oracle_camera *cam, const oracle_march
 /* ---- _bloom_kernel: render.py:3022-3114 ----------------------------------
  * image (W,H,3) is modified in place by the last loop exactly as the
  * reference does; bright and blur are (W,H,3) scratch/outputs. */
-ORACLE_API void oracle_bloom(float *image, float *bright, float *blur, int32_t w, int32_t h,
-                             float threshold, float intensity, int32_t kernel_radius, float sigma_scale)
+ORACLE_API void oracle_bloom(f32 *image, f32 *bright, f32 *blur, int32_t w, int32_t h,
+                             f32 threshold, f32 intensity, int32_t kernel_radius, f32 sigma_scale)
 {
 #define AT(buf, i, j) ((buf) + ((size_t)(i) * h + (j)) * 3)
 #ifdef _OPENMP
@@ -648,9 +669,9 @@ ORACLE_API void oracle_bloom(float *image, float *bright, float *blur, int32_t w
 #endif
     for (int32_t i = 0; i < w; ++i)
         for (int32_t j = 0; j < h; ++j) {
-            const float *col = AT(image, i, j);
+            const f32 *col = AT(image, i, j);
             float lum = col[0] * 0.2126f + col[1] * 0.7152f + col[2] * 0.0722f;
-            float *b = AT(bright, i, j);
+            f32 *b = AT(bright, i, j);
             if (lum > threshold) { b[0] = col[0]; b[1] = col[1]; b[2] = col[2]; }
             else { b[0] = 0.0f; b[1] = 0.0f; b[2] = 0.0f; }
         }
@@ -664,7 +685,7 @@ ORACLE_API void oracle_bloom(float *image, float *bright, float *blur, int32_t w
                 int32_t ni = i + dx;
                 if (0 <= ni && ni < w) {
                     float dist_sq = (float)(dx * dx);
-                    const float *col = AT(bright, ni, j);
+                    const f32 *col = AT(bright, ni, j);
                     float w_r = expf(-dist_sq / (25.0f * sigma_scale));
                     float w_g = expf(-dist_sq / (80.0f * sigma_scale));
                     float w_b = expf(-dist_sq / (1600.0f * sigma_scale));
@@ -672,11 +693,11 @@ ORACLE_API void oracle_bloom(float *image, float *bright, float *blur, int32_t w
                     weight_r += w_r; weight_g += w_g; weight_b += w_b;
                 }
             }
-            float *o = AT(blur, i, j);
+            f32 *o = AT(blur, i, j);
             if (weight_r > 0.0f) { o[0] = sum_r / weight_r; o[1] = sum_g / weight_g; o[2] = sum_b / weight_b; }
             else { o[0] = 0; o[1] = 0; o[2] = 0; }
         }
-    memcpy(bright, blur, (size_t)w * h * 3 * sizeof(float));
+    memcpy(bright, blur, (size_t)w * h * 3 * sizeof(f32));
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
@@ -687,7 +708,7 @@ ORACLE_API void oracle_bloom(float *image, float *bright, float *blur, int32_t w
                 int32_t nj = j + dy;
                 if (0 <= nj && nj < h) {
                     float dist_sq = (float)(dy * dy);
-                    const float *col = AT(bright, i, nj);
+                    const f32 *col = AT(bright, i, nj);
                     float w_r = expf(-dist_sq / (25.0f * sigma_scale));
                     float w_g = expf(-dist_sq / (80.0f * sigma_scale));
                     float w_b = expf(-dist_sq / (1600.0f * sigma_scale));
@@ -695,24 +716,24 @@ ORACLE_API void oracle_bloom(float *image, float *bright, float *blur, int32_t w
                     weight_r += w_r; weight_g += w_g; weight_b += w_b;
                 }
             }
-            float *o = AT(blur, i, j);
+            f32 *o = AT(blur, i, j);
             if (weight_r > 0.0f) { o[0] = sum_r / weight_r; o[1] = sum_g / weight_g; o[2] = sum_b / weight_b; }
             else { o[0] = 0; o[1] = 0; o[2] = 0; }
         }
     for (int32_t i = 0; i < w; ++i)
         for (int32_t j = 0; j < h; ++j) {
-            float *c = AT(image, i, j);
-            const float *b = AT(blur, i, j);
+            f32 *c = AT(image, i, j);
+            const f32 *b = AT(blur, i, j);
             for (int k = 0; k < 3; ++k) c[k] = clampf(c[k] + b[k] * intensity, 0.0f, 1.0f);
         }
 #undef AT
 }
 
 /* ---- _compose_disk_texture_kernel: render.py:3169-3257 ------------------- */
-ORACLE_API void oracle_compose_disk_texture(float *disk_tex, const float *comp, const float *omega,
-                                            const float *edge, const float *stats, const float *row_stats,
-                                            int32_t n_r, int32_t n_phi, float t_offset, int32_t enable_rt,
-                                            float color_temp_val)
+ORACLE_API void oracle_compose_disk_texture(f32 *disk_tex, const f32 *comp, const f32 *omega,
+                                            const f32 *edge, const f32 *stats, const f32 *row_stats,
+                                            int32_t n_r, int32_t n_phi, f32 t_offset, int32_t enable_rt,
+                                            f32 color_temp_val)
 {
     float density_p98 = stats[0];
     float struct_scale = stats[1];
@@ -758,7 +779,7 @@ ORACLE_API void oracle_compose_disk_texture(float *disk_tex, const float *comp, 
             float bb_b = fminf(bb.z, bb.x);
             float lum = fminf(fmaxf(sqrtf(temp_aniso), 0.0f), 1.0f);
 
-            float *o = disk_tex + ((size_t)ri * n_phi + phi_i) * 4;
+            f32 *o = disk_tex + ((size_t)ri * n_phi + phi_i) * 4;
             o[0] = fminf(fmaxf(bb.x * lum, 0.0f), 1.0f);
             o[1] = fminf(fmaxf(bb.y * lum, 0.0f), 1.0f);
             o[2] = fminf(fmaxf(bb_b * lum, 0.0f), 1.0f);
@@ -769,15 +790,15 @@ ORACLE_API void oracle_compose_disk_texture(float *disk_tex, const float *comp, 
 /* ---- mip kernels: render.py:3261-3283, driven as at render.py:3761-3767 ---
  * mips: (levels, n_r, n_phi, 4) padded storage, must be zero-initialised by the
  * caller (Taichi fields start at zero); builds levels 0..levels-1. */
-ORACLE_API void oracle_build_mips(float *mips, const float *base, int32_t n_r, int32_t n_phi, int32_t levels)
+ORACLE_API void oracle_build_mips(f32 *mips, const f32 *base, int32_t n_r, int32_t n_phi, int32_t levels)
 {
     const size_t lvl = (size_t)n_r * n_phi * 4;
-    memcpy(mips, base, lvl * sizeof(float));
+    memcpy(mips, base, lvl * sizeof(f32));
     int32_t h = n_r, w = n_phi;
     for (int32_t level = 1; level < levels; ++level) {
         int32_t dst_h = h / 2, dst_w = w / 2;
-        const float *src = mips + (size_t)(level - 1) * lvl;
-        float *dst = mips + (size_t)level * lvl;
+        const f32 *src = mips + (size_t)(level - 1) * lvl;
+        f32 *dst = mips + (size_t)level * lvl;
         for (int32_t ri = 0; ri < dst_h; ++ri)
             for (int32_t pi = 0; pi < dst_w; ++pi)
                 for (int c = 0; c < 4; ++c) {
@@ -794,8 +815,8 @@ ORACLE_API void oracle_build_mips(float *mips, const float *base, int32_t n_r, i
 /* ---- _generate_background_kernel: render.py:3332-3451 -------------------- */
 static inline float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
-ORACLE_API void oracle_generate_background(float *comp, int32_t n_r, int32_t n_phi, int32_t az_freq,
-                                           float az_shear, float r_inner, float r_outer, float t)
+ORACLE_API void oracle_generate_background(f32 *comp, int32_t n_r, int32_t n_phi, int32_t az_freq,
+                                           f32 az_shear, f32 r_inner, f32 r_outer, f32 t)
 {
     const float pi2 = 2.0f * PI_F;
     const size_t plane = (size_t)n_r * n_phi;

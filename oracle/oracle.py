@@ -50,8 +50,9 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def load(fast: bool = False) -> C.CDLL:
-    name = "liboracle_fast.so" if fast else "liboracle.so"
+def load(fast=False) -> C.CDLL:
+    """fast: False -> strict f32 checker; True -> -ffast-math/OpenMP build; "f64" -> binary64 build."""
+    name = {False: "liboracle.so", True: "liboracle_fast.so", "f64": "liboracle_f64.so"}[fast]
     if name in _libs:
         return _libs[name]
     path = os.path.join(_BUILD, name)
