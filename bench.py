@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="fhd", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tile-kernel", action="store_true", help="A/B: tile schedule instead of persistent refill")
+    ap.add_argument("--persistent", action="store_true", help="A/B: persistent waves + queue refill instead of the tile schedule")
     ap.add_argument("--math", default=None, choices=["fast", "strict"], help="march arithmetic (default: the renderer's)")
     return ap.parse_args()
 
@@ -107,7 +107,7 @@ def main():
         renderer.sync()
 
     # frames sharded round-robin over ranks (configs[4]); the camera is the static default pov
-    compaction = not args.tile_kernel
+    compaction = args.persistent
     for _ in range(args.warmup):
         renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction)
     renderer.timing_reset()
@@ -155,7 +155,7 @@ def main():
                                    f"fov {wl['fov']:g}, step_size {wl['step_size']}, anti_alias {wl['anti_alias']}",
                        "scene": scene_note, "frames_per_rank": args.steps,
                        "sharding": "independent frames per rank, no collective",
-                       "march_schedule": "tile" if args.tile_kernel else "persistent+refill",
+                       "march_schedule": "persistent+refill" if args.persistent else "tile",
                        "march_math": renderer.math,
                        "ray_steps_per_frame": int(steps_per_frame), "steps_per_ray": steps_per_frame / pixels},
             "kernel_ms": {"march": march_ms, "bloom_and_combine": bloom_ms, "frames_timed": n_frames,

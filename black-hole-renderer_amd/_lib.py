@@ -23,7 +23,7 @@ SYMBOLS = (
     "bhr_set_skybox", "bhr_set_disk_texture", "bhr_get_disk_texture", "bhr_get_disk_mip", "bhr_num_mip_levels",
     "bhr_bg_init", "bhr_generate_background", "bhr_set_entity_staging", "bhr_set_comp", "bhr_read_comp",
     "bhr_fill_comp_slice", "bhr_set_compose_stats", "bhr_compose_texture", "bhr_eval_noise", "bhr_render",
-    "bhr_read_layer", "bhr_read_final_u8", "bhr_get_counters", "bhr_timing_reset", "bhr_group_render",
+    "bhr_read_layer", "bhr_read_final_u8", "bhr_get_counters", "bhr_timing_reset", "bhr_selftest", "bhr_group_render",
 )
 
 
@@ -95,6 +95,7 @@ def load() -> C.CDLL:
     lib.bhr_read_final_u8.argtypes = [P, C.POINTER(C.c_uint8)]
     lib.bhr_get_counters.argtypes = [P, C.POINTER(Counters)]
     lib.bhr_timing_reset.argtypes = [P]
+    lib.bhr_selftest.argtypes = [P, C.POINTER(C.c_uint64)]
     lib.bhr_group_render.argtypes = [C.POINTER(P), I32, C.POINTER(Camera), C.c_uint32, F]
     for name in SYMBOLS:
         fn = getattr(lib, name)

@@ -461,6 +461,17 @@ int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {
     return BHR_OK;
 }
 
+int32_t bhr_selftest(bhr_ctx *ctx, uint64_t out[4]) {
+    if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_selftest: bad argument");
+    BHR_TRY(use_device(ctx));
+    unsigned long long *d = nullptr;
+    BHR_TRY(dev_alloc(&d, 4));
+    int32_t rc = bhr_selftest_strict(ctx, d);
+    if (rc == BHR_OK) rc = download(ctx, out, d, 4 * sizeof(unsigned long long));
+    (void)hipFree(d);
+    return rc;
+}
+
 int32_t bhr_timing_reset(bhr_ctx *ctx) {
     if (!ctx) return bhr_fail(BHR_ERR_INVALID, "null ctx");
     BHR_TRY(use_device(ctx));

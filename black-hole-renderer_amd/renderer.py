@@ -314,6 +314,12 @@ class HipRenderer:
             final = apply_lens_flare(final, self.read_layer(_lib.LAYER_DISK))
         return final
 
+    def selftest(self) -> dict:
+        """Device check of the strict march's exact sqrt / divide sequences (bhr_selftest)."""
+        out = (C.c_uint64 * 4)()
+        _lib.check(self._lib.bhr_selftest(self._ctx, out))
+        return {"bad_sqrt": out[0], "bad_div": out[1], "bad_div6": out[2], "checked": out[3]}
+
     def timing_reset(self) -> None:
         _lib.check(self._lib.bhr_timing_reset(self._ctx))
 

@@ -180,3 +180,16 @@ def test_group_render_tiles_match_single_context(hip_lib):
     np.testing.assert_allclose(out, ref, atol=1e-6, rtol=0)
     for t in tiles + [full]:
         t.close()
+
+
+def test_exact_arithmetic_selftest(hip_lib):
+    """The strict march's hand-written sqrt / divide / divide-by-6 sequences equal hipcc's IEEE
+    sqrtf and operator/ on the device: every f32 in [2^-40, 2^40) for sqrt and x/6, 2^30 random
+    operand pairs for the general divide."""
+    from bhr_amd import HipRenderer
+    s = scenes.SCENES["default"]
+    hip = HipRenderer(64, 36, scenes.analytic_skybox(32, 64), scenes.analytic_disk(16, 32), **s["kw"])
+    r = hip.selftest()
+    assert r["checked"] > 3 * (80 << 23)
+    assert (r["bad_sqrt"], r["bad_div"], r["bad_div6"]) == (0, 0, 0), r
+    hip.close()
