@@ -1,0 +1,157 @@
+"""CLI surface and drivers.  CPU part: flag names/defaults/validation of the reference
+(render.py:4518-4616, tests/unit/test_orbit_degrees.py) and the multi-GPU partition helpers.
+GPU part: render_image on the e2e scene, a short video with resume and frame sharding."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_defaults_match_reference():
+    from bhr_amd import cli
+    a = cli.parse_args([])
+    assert a.pov == [6, 0, 0.5] and a.fov == 90 and a.resolution == "fhd"
+    assert a.output == "output/blackhole.png" and a.step_size == 0.1 and a.r_max == 10 and a.n_stars == 6000
+    assert a.disk_inner_radius == 2.0 and a.disk_outer_radius == 15.0 and a.disk_tilt == 0.0
+    assert a.anti_alias == "disabled" and a.aa_strength == 1.0 and not a.lens_flare
+    assert a.n_frames == 3600 and a.fps == 36 and a.orbit_degrees == 360.0 and a.disk_rotation_speed == 0.1
+    assert a.device == "hip" and a.gpus == 1
+    b = cli.parse_args(["--ar1", "3", "--ar2", "9", "-r", "8k", "-s", "0.05", "--anti_alias", "lod_radius",
+                        "--video", "--orbit", "--n_frames", "12", "-o", "x/y.mp4", "--pov", "1", "2", "3"])
+    assert (b.disk_inner_radius, b.disk_outer_radius, b.resolution, b.step_size) == (3.0, 9.0, "8k", 0.05)
+    assert b.video and b.orbit and b.n_frames == 12 and b.pov == [1.0, 2.0, 3.0]
+    assert cli.RESOLUTIONS["8k"] == (7680, 4320) and cli.RESOLUTIONS["fhd"] == (1920, 1080)
+
+
+@pytest.mark.parametrize("argv,msg", [
+    (["--fov", "0"], "FOV"), (["--fov", "180"], "FOV"), (["--ar1", "5", "--ar2", "5"], "disk_inner_radius"),
+    (["-s", "0"], "step_size"), (["--aa_strength", "0.4"], "aa_strength"), (["--aa_strength", "2.1"], "aa_strength"),
+    (["--n_frames", "0"], "n_frames"), (["--fps", "0"], "fps"), (["--orbit_degrees", "inf"], "orbit_degrees"),
+    (["--orbit_degrees", "nan"], "orbit_degrees"), (["--disk_texture", "x.png", "--video"], "disk_texture"),
+    (["--device", "cpu"], "no CPU path"), (["--gpus", "0"], "gpus"), (["--interactive"], "interactive"),
+])
+def test_cli_validation_errors(argv, msg):
+    from bhr_amd import cli
+    with pytest.raises(ValueError, match=msg):
+        cli.validate_args(cli.parse_args(argv))
+
+
+def test_cli_negative_orbit_degrees_is_valid():
+    from bhr_amd import cli
+    cli.validate_args(cli.parse_args(["--orbit_degrees", "-90"]))
+
+
+def test_row_blocks_and_frame_shards():
+    from bhr_amd.multigpu import frames_of_rank, row_blocks
+    assert row_blocks(4320, 8) == [(540 * k, 540 * (k + 1)) for k in range(8)]
+    b = row_blocks(1080, 7)
+    assert b[0][0] == 0 and b[-1][1] == 1080 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    assert max(e - s for s, e in b) - min(e - s for s, e in b) <= 1
+    with pytest.raises(ValueError):
+        row_blocks(4, 8)
+    frames = sorted(f for r in range(8) for f in frames_of_rank(3600, r, 8))
+    assert frames == list(range(3600))
+    assert list(frames_of_rank(10, 3, 4)) == [3, 7]
+
+
+# --------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_render_image_e2e_scene(oracle, tmp_path):
+    """tests/e2e_render.py:25-43 scene end to end (lifecycle texture + skybox + march + bloom) against
+    the oracle fed with the same device-generated texture."""
+    from bhr_amd import HipRenderer, drivers
+    from bhr_amd.skybox import generate_skybox
+    from bhr_amd.textures import compute_disk_texture_resolution
+    kw = dict(step_size=0.1, r_max=10, r_disk_inner=2.0, r_disk_outer=3.5, disk_tilt=15, anti_alias="disabled")
+    img = drivers.render_image(320, 180, [6, 0, 0.5], 60, n_stars=100, lens_flare=False, **kw)
+    assert img.shape == (180, 320, 3) and img.dtype == np.float32
+    # same pipeline by hand, then the oracle on the resulting texture
+    n_phi, n_r = compute_disk_texture_resolution(320, 180, [6, 0, 0.5], 60, 2.0, 3.5)
+    assert (n_r, n_phi) == (128, 336)
+    sky = generate_skybox(2048, 1024, seed=42, n_stars=100)
+    r = HipRenderer(320, 180, sky, np.zeros((n_r, n_phi, 4), dtype=np.float32), **kw)
+    fac = drivers.init_lifecycle_system(r, n_r, n_phi, seed=42)
+    drivers.advance_lifecycle_frame(r, fac, t=0.0, dt=0.0, recompute_stats=True)
+    tex = r.disk_texture_field.to_numpy()
+    np.testing.assert_array_equal(r.render([6, 0, 0.5], 60), img)          # deterministic end to end
+    ref = oracle.OracleRenderer(320, 180, sky, tex, **kw).render([6, 0, 0.5], 60)
+    rmse = np.sqrt(np.mean((img.astype(np.float64) - ref) ** 2, axis=(0, 1)))
+    assert (rmse <= 5e-6).all(), rmse
+    drivers.save_image(img, str(tmp_path / "o" / "e2e.png"))
+    from PIL import Image
+    png = np.array(Image.open(tmp_path / "o" / "e2e.png"))
+    np.testing.assert_array_equal(png, (np.clip(img, 0, 1) * 255).astype(np.uint8))
+    r.close()
+
+
+@pytest.mark.gpu
+def test_lens_flare_and_aa_image(oracle):
+    from bhr_amd import HipRenderer, scenes
+    from bhr_amd.flare import apply_lens_flare
+    sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
+    kw = dict(step_size=0.1, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=25.0, anti_alias="lod_radius")
+    r = HipRenderer(256, 144, sky, tex, lens_flare=True, **kw)
+    img = r.render([6, 0, 0.5], 90)
+    o = oracle.OracleRenderer(256, 144, sky, tex, **kw)
+    ref, _, rdisk, _ = o.render([6, 0, 0.5], 90, parts=True)
+    want = apply_lens_flare(ref, np.ascontiguousarray(rdisk.transpose(1, 0, 2)))
+    assert np.abs(img - want).max() < 2e-4 and np.abs(want - ref).max() > 0.01   # the flare is really there
+    r.close()
+
+
+@pytest.mark.gpu
+def test_video_frames_resume_and_sharding(tmp_path):
+    """render_video: PNG frames, progress.json format (render.py:4380-4403, 4469-4472), resume skips
+    finished frames, and 2-way frame sharding produces the same frames as one rank."""
+    from PIL import Image
+    from bhr_amd import drivers
+
+    def run(out, n_frames=6, rank=0, world=1, resume=False):
+        r, _, _, _ = drivers.make_renderer(160, 90, [6, 0, 0.5], 90, n_stars=50, tex_w=256, tex_h=128)
+        drivers.render_video(r, 160, 90, n_frames=n_frames, fps=4, output_path=out, fov=90, static_cam_pos=[6, 0, 0.5],
+                             orbit=True, resume=resume, disk_rotation_speed=0.1, orbit_degrees=90.0, rank=rank,
+                             world=world, assemble=False)
+        r.close()
+        return drivers._frames_dir(out)
+
+    out1 = str(tmp_path / "a" / "v.mp4")
+    d1 = run(out1)
+    frames1 = [np.array(Image.open(os.path.join(d1, f"frame_{k:04d}.png"))) for k in range(6)]
+    assert frames1[0].shape == (90, 160, 3) and frames1[0].max() > 10
+    assert any((frames1[0] != frames1[5]).ravel())                          # the camera moved
+    prog = json.load(open(os.path.join(d1, "progress.json")))
+    assert sorted(prog["completed"]) == list(range(6))
+    assert prog["params"] == {"n_frames": 6, "fov": 90, "orbit": True, "disk_rotation_speed": 0.1, "orbit_degrees": 90.0}
+
+    # resume: drop two frames from the progress file, re-run, only those are re-rendered -- identically
+    os.remove(os.path.join(d1, "frame_0003.png"))
+    os.remove(os.path.join(d1, "frame_0005.png"))
+    json.dump({"params": prog["params"], "completed": [0, 1, 2, 4]}, open(os.path.join(d1, "progress.json"), "w"))
+    mtime = os.path.getmtime(os.path.join(d1, "frame_0001.png"))
+    run(out1, resume=True)
+    assert os.path.getmtime(os.path.join(d1, "frame_0001.png")) == mtime
+    for k in (3, 5):
+        np.testing.assert_array_equal(np.array(Image.open(os.path.join(d1, f"frame_{k:04d}.png"))), frames1[k])
+
+    # two ranks, frames f % 2 == rank: same pixels as the single-rank run
+    out2 = str(tmp_path / "b" / "v.mp4")
+    d2 = run(out2, rank=0, world=2)
+    run(out2, rank=1, world=2)
+    for k in range(6):
+        np.testing.assert_array_equal(np.array(Image.open(os.path.join(d2, f"frame_{k:04d}.png"))), frames1[k])
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path):
+    out = tmp_path / "cli.png"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "render.py"), "-r", "sd", "--n_stars", "200", "-o", str(out),
+                        "--disk_tilt", "10"], capture_output=True, text=True, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    from PIL import Image
+    img = np.array(Image.open(out))
+    assert img.shape == (360, 640, 3) and img.max() > 50
