@@ -90,11 +90,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from bhr_amd import distributed as D
+    dist = D.init("nccl", local_rank) if world > 1 else None   # backend "nccl" is RCCL on ROCm
 
     from bhr_amd import workloads
     wl = WORKLOADS[args.workload]
@@ -120,15 +117,23 @@ def main():
 
     c = renderer.counters()
     steps_per_frame = c["ray_steps"]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        s = torch.tensor([float(steps_per_frame)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        total_steps = float(s.item()) * args.steps
-    else:
-        total_steps = float(steps_per_frame) * args.steps
+
+    # same scene, same process, the other arithmetic: reported beside the headline, never as `value`
+    other = "fast" if renderer.math == "strict" else "strict"
+    n_other = max(args.steps // 4, 10)
+    for _ in range(3):
+        renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, math=other)
+    renderer.timing_reset()
+    renderer.sync()
+    t1 = time.perf_counter()
+    for _ in range(n_other):
+        renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, math=other)
+    renderer.sync()
+    el_other = time.perf_counter() - t1
+    co = renderer.counters()
+    # MAX over ranks of the time, SUM over ranks of the ray-steps each rank marched in the timed region
+    elapsed, total_steps = D.aggregate_throughput(elapsed, float(c["ray_steps_sum"]) if c["frames_timed"] == args.steps
+                                                  else float(steps_per_frame) * args.steps, dist, device="cuda")
 
     if rank == 0:
         n_frames = c["frames_timed"]
@@ -168,6 +173,9 @@ def main():
                               "unit": "TFLOP/s", "frac": valu_tflops / VALU_FP32_PEAK_TFLOPS,
                               "flop_per_ray_step": MARCH_FLOP_PER_RAY_STEP},
         }
+        out["other_math"] = {"math": other, "value": co["ray_steps"] * n_other / el_other / 1e6, "unit": "Mray-steps/s",
+                             "fps": n_other / el_other, "march_ms": co["march_ms_sum"] / max(co["frames_timed"], 1),
+                             "note": "informational A/B in the same process; `value` above is the default (parity-certified) arithmetic"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, sky, tex)
         print(json.dumps(out))

@@ -13,7 +13,7 @@ from .build import library_path
 BHR_OK = 0
 BHR_ERR_INVALID, BHR_ERR_NO_DEVICE, BHR_ERR_HIP, BHR_ERR_STATE, BHR_ERR_NOMEM = -1, -2, -3, -4, -5
 
-SKIP_DIFFERENTIALS, SKIP_BLOOM, PERSISTENT = 1, 2, 4
+SKIP_DIFFERENTIALS, SKIP_BLOOM, PERSISTENT, FORCE_FAST, FORCE_STRICT = 1, 2, 4, 8, 16
 MATH_FAST, MATH_STRICT = 0, 1
 LAYER_FINAL, LAYER_BG, LAYER_DISK, LAYER_BLUR = 0, 1, 2, 3
 

@@ -112,12 +112,15 @@ def main(argv=None) -> int:
                              resume=args.resume, disk_rotation_speed=args.disk_rotation_speed,
                              orbit_degrees=args.orbit_degrees, rank=rank, world=world)
         if world > 1:
-            import torch.distributed as dist
-            if not dist.is_initialized():
-                dist.init_process_group(backend="gloo")
+            from . import distributed as D
+            dist = D.init("gloo")          # a barrier is all the ranks exchange: frames are independent
             dist.barrier()
             if rank == 0:
-                drivers.assemble_video(drivers._frames_dir(args.output), args.n_frames, args.fps, args.output)
+                done = D.merge_progress(drivers._frames_dir(args.output), world)
+                if len(done) == args.n_frames:
+                    drivers.assemble_video(drivers._frames_dir(args.output), args.n_frames, args.fps, args.output)
+                else:
+                    print(f"Warning: only {len(done)}/{args.n_frames} frames completed. Run again with --resume.")
             dist.barrier()
         renderer.close()
         return 0

@@ -850,7 +850,12 @@ int32_t BHR_MARCH_RESOURCES(int32_t *vgprs, int32_t *lds, int32_t diff) {
 int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     const bhr_config &c = ctx->cfg;
 #if !BHR_MARCH_STRICT
-    if (c.math_mode == BHR_MATH_STRICT) return bhr_launch_march_strict(ctx, cam, flags);
+    {
+        bool strict = c.math_mode == BHR_MATH_STRICT;
+        if (flags & BHR_FORCE_FAST) strict = false;
+        if (flags & BHR_FORCE_STRICT) strict = true;
+        if (strict) return bhr_launch_march_strict(ctx, cam, flags);
+    }
 #endif
     if (!ctx->d_skybox) return bhr_fail(BHR_ERR_STATE, "bhr_render: no skybox set (bhr_set_skybox)");
     if (!ctx->d_mips) return bhr_fail(BHR_ERR_STATE, "bhr_render: no disk texture set (bhr_set_disk_texture)");

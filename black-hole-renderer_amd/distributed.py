@@ -1,0 +1,54 @@
+"""One-process-per-GPU helpers (torch.distributed over RCCL on the GPUs, gloo in CPU tests).
+
+The path shards by independent units -- frames (video, bench) or row blocks -- so there is no
+data-path collective; the only exchanges are the timing/throughput reduction of bench.py and a
+barrier before rank 0 assembles a video."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+
+def env_rank() -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment (1-process defaults)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend: str, local_rank: int = 0):
+    """init_process_group with the rendezvous taken from MASTER_ADDR/MASTER_PORT (127.0.0.1 on one node)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist
+    kw = {}
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        kw["device_id"] = torch.device("cuda", local_rank)
+    dist.init_process_group(backend=backend, **kw)
+    return dist
+
+
+def aggregate_throughput(elapsed_s: float, units: float, dist=None, device="cpu") -> Tuple[float, float]:
+    """Whole-job figures for weak scaling: (max over ranks of the elapsed time, sum over ranks of the
+    units each rank processed).  Without a process group returns the inputs."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(elapsed_s), float(units)
+    import torch
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    u = torch.tensor([units], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
+def merge_progress(temp_dir: str, world: int) -> set:
+    """Union of the per-rank progress files written by drivers.render_video when world > 1."""
+    import json
+    done = set()
+    for r in range(world):
+        p = os.path.join(temp_dir, f"progress.rank{r}.json")
+        if os.path.isfile(p):
+            with open(p) as f:
+                done |= set(json.load(f).get("completed", []))
+    return done

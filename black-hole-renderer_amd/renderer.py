@@ -277,17 +277,18 @@ class HipRenderer:
         return cam
 
     @staticmethod
-    def _flags(skip_differentials: bool, skip_bloom: bool, compaction: bool = False) -> int:
+    def _flags(skip_differentials: bool, skip_bloom: bool, compaction: bool = False, math=None) -> int:
         return ((_lib.SKIP_DIFFERENTIALS if skip_differentials else 0) | (_lib.SKIP_BLOOM if skip_bloom else 0)
-                | (_lib.PERSISTENT if compaction else 0))
+                | (_lib.PERSISTENT if compaction else 0)
+                | {None: 0, "fast": _lib.FORCE_FAST, "strict": _lib.FORCE_STRICT}[math])
 
     def render_async(self, cam_pos, fov: float, frame: int = 0, skip_differentials: bool = False,
-                     skip_bloom: bool = False, compaction: bool = False) -> None:
+                     skip_bloom: bool = False, compaction: bool = False, math=None) -> None:
         """Launch march + bloom + combine; the frame stays in HBM (counterpart of render_to_field,
         render.py:3819-3863, without the GUI flip)."""
         cam = self.camera_uniforms(cam_pos, fov, frame)
         _lib.check(self._lib.bhr_render(self._ctx, C.byref(cam), self._flags(skip_differentials, skip_bloom,
-                                                                            compaction)))
+                                                                            compaction, math)))
 
     def sync(self) -> None:
         _lib.check(self._lib.bhr_sync(self._ctx))

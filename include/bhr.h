@@ -88,6 +88,8 @@ typedef struct {
 #define BHR_SKIP_DIFFERENTIALS 1u  /* render(skip_differentials=True): plain bilinear disk lookup */
 #define BHR_SKIP_BLOOM         2u  /* render(skip_bloom=True) */
 #define BHR_PERSISTENT         4u  /* persistent waves + queue refill instead of the tile schedule */
+#define BHR_FORCE_FAST         8u  /* this call only: fast arithmetic regardless of bhr_config.math_mode */
+#define BHR_FORCE_STRICT      16u  /* this call only: strict arithmetic regardless of bhr_config.math_mode */
 
 /* selectors for bhr_read_layer */
 typedef enum {

@@ -15,13 +15,12 @@ def find(sub, suffix):
 
 
 def short(name):
-    name = name.split("(")[0]
     for k in ("march_tile_kernel", "march_persistent_kernel", "bloom_h_kernel", "bloom_v_kernel", "background_kernel",
               "compose_kernel", "mip_down_kernel", "quantize_u8_kernel", "bloom_w"):
         if k in name:
             tpl = "<diff>" if "ILb1E" in name or "<true>" in name else ""
             return k + tpl
-    return name[-60:]
+    return name.split("(")[0][-60:]
 
 
 print(f"# rocprofv3 summary: {os.path.basename(out)}\n")
