@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/bhr.h"
+#include "../../include/bhr_disk_v2.h"
 
 #define BHR_NUM_MIP_LEVELS 5  // generate_disk_mipmaps(levels=4) => 5 stored levels (render.py:2239-2240)
 #define BHR_WAVE 64
@@ -128,3 +129,6 @@ int32_t bhr_launch_compose(bhr_ctx *ctx, float t_offset, int32_t enable_rt, floa
 int32_t bhr_launch_fill(bhr_ctx *ctx, float *dst, int64_t n, float v);
 int32_t bhr_launch_noise(bhr_ctx *ctx, int64_t n, int32_t mode, int32_t octaves, float pers, float lac);
 int32_t bhr_march_resources(int32_t *vgprs, int32_t *lds, int32_t diff);
+int32_t bhr_launch_disk_v2(bhr_ctx *ctx, const bhr_disk_v2_params *p, const double *d_r, const double *d_z,
+                           const double *d_phi, int64_t n, int32_t field, double *d_out, double *d_aux,
+                           double *d_maxabs, double norm0, double norm1);

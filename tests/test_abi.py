@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    text = open(os.path.join(ROOT, "include", "bhr.h")).read()
+    inc = os.path.join(ROOT, "include")
+    text = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     return sorted(set(re.findall(r"BHR_API\s+[\w\s\*]+?\b(bhr_[a-z0-9_]+)\s*\(", text)))
 
 
