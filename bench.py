@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--workload", default="fhd", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--persistent", action="store_true", help="A/B: persistent waves + queue refill instead of the tile schedule")
+    ap.add_argument("--no-other-math", action="store_true", help="skip the informational A/B leg (profiling)")
     ap.add_argument("--math", default=None, choices=["fast", "strict"], help="march arithmetic (default: the renderer's)")
     return ap.parse_args()
 
@@ -120,8 +121,8 @@ def main():
 
     # same scene, same process, the other arithmetic: reported beside the headline, never as `value`
     other = "fast" if renderer.math == "strict" else "strict"
-    n_other = max(args.steps // 4, 10)
-    for _ in range(3):
+    n_other = 0 if args.no_other_math else max(args.steps // 4, 10)
+    for _ in range(3 if n_other else 0):
         renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, math=other)
     renderer.timing_reset()
     renderer.sync()
@@ -130,7 +131,7 @@ def main():
         renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, math=other)
     renderer.sync()
     el_other = time.perf_counter() - t1
-    co = renderer.counters()
+    co = renderer.counters() if n_other else None
     # MAX over ranks of the time, SUM over ranks of the ray-steps each rank marched in the timed region
     elapsed, total_steps = D.aggregate_throughput(elapsed, float(c["ray_steps_sum"]) if c["frames_timed"] == args.steps
                                                   else float(steps_per_frame) * args.steps, dist, device="cuda")
@@ -173,7 +174,8 @@ def main():
                               "unit": "TFLOP/s", "frac": valu_tflops / VALU_FP32_PEAK_TFLOPS,
                               "flop_per_ray_step": MARCH_FLOP_PER_RAY_STEP},
         }
-        out["other_math"] = {"math": other, "value": co["ray_steps"] * n_other / el_other / 1e6, "unit": "Mray-steps/s",
+        if n_other:
+          out["other_math"] = {"math": other, "value": co["ray_steps"] * n_other / el_other / 1e6, "unit": "Mray-steps/s",
                              "fps": n_other / el_other, "march_ms": co["march_ms_sum"] / max(co["frames_timed"], 1),
                              "note": "informational A/B in the same process; `value` above is the default (parity-certified) arithmetic"}
         if not args.no_cpu_baseline and world == 1:

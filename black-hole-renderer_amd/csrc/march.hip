@@ -29,6 +29,8 @@
 //                   the reference's order with IEEE sqrt and divide, so that positions, step
 //                   counts and hit points are bit-identical to a strict f32 evaluation of
 //                   render.py:2854-3006 (selected with bhr_config.math_mode = 1).
+#include <stdlib.h>
+
 #include "bhr_internal.h"
 
 #ifndef BHR_MARCH_STRICT
@@ -75,31 +77,31 @@ __device__ __forceinline__ float div6(float x) {
     return fmaf(r, c, q);
 }
 
-// IEEE-754 correctly rounded sqrt and divide for NORMAL-range operands (|x| in [2^-60, 2^60], no
-// overflow of the quotient): the instruction sequences hipcc emits for sqrtf / operator/ minus the
-// denormal / overflow scaling (v_div_scale, v_div_fixup, the 2^32 pre-scale of sqrt), which the
-// bounded quantities of the march (r^2 in [0.5, 1e6], |L2|/r^5, 1/r) never need.  Saves 5 + 3
-// instructions per call, 43 per RK4 step.  bhr_selftest() checks them against the compiler's
-// IEEE sequences on the GPU (exhaustively for sqrt, 2^30 random pairs for divide).
+// IEEE-754 correctly rounded sqrt, reciprocal and divide for NORMAL-range operands (no overflow or
+// underflow of the result), as Newton/Markstein steps on the hardware approximations:
+//   sqrt(x): y = v_rsq(x); s = x y; s' = s + (x - s s)(y/2)            5 instructions
+//   1/b    : y = v_rcp(b); y' = y + (1 - b y) y                        3 instructions
+//   a/b    : q = a y'; q' = q + (a - b q) y'                           6 instructions
+// hipcc's own IEEE sequences take 14 / 11 / 11 (they also handle denormals and overflow, which the
+// bounded quantities of the march -- r^2 in [0.5, 1e6], |L2|/r^5, 1/r -- never produce).  The
+// residuals are exact thanks to FMA; that the final rounding is the correct one was established
+// exhaustively on gfx950 (tools/exact_search.hip: every f32 in [2^-80, 2^80) for sqrt and 1/b, 1.7e10
+// random + adversarial pairs for a/b, zero mismatches against sqrtf and operator/), and
+// bhr_selftest() repeats the check on the device it runs on.  Saves 64 instructions per RK4 step.
 __device__ __forceinline__ float sqrt_rn(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);                 // <= 1 ulp
-    float s_lo = __int_as_float(__float_as_int(s) - 1);
-    float s_hi = __int_as_float(__float_as_int(s) + 1);
-    float r_lo = fmaf(-s_lo, s, x);
-    float r_hi = fmaf(-s_hi, s, x);
-    s = r_lo <= 0.0f ? s_lo : s;
-    s = r_hi > 0.0f ? s_hi : s;
-    return s;
+    float y = __builtin_amdgcn_rsqf(x);
+    float s = x * y;
+    float r = fmaf(-s, s, x);
+    return fmaf(r, 0.5f * y, s);
+}
+__device__ __forceinline__ float rcp_rn(float b) {
+    float y = __builtin_amdgcn_rcpf(b);
+    return fmaf(fmaf(-b, y, 1.0f), y, y);
 }
 __device__ __forceinline__ float div_rn(float a, float b) {
-    float y = __builtin_amdgcn_rcpf(b);
-    float e = fmaf(-b, y, 1.0f);
-    y = fmaf(e, y, y);
+    float y = rcp_rn(b);
     float q = a * y;
-    float r = fmaf(-b, q, a);
-    q = fmaf(r, y, q);
-    r = fmaf(-b, q, a);
-    return fmaf(r, y, q);
+    return fmaf(fmaf(-b, q, a), y, q);
 }
 // x + 0.5 y and x + 2 y: the products are exact, so one FMA rounds exactly like mul-then-add
 __device__ __forceinline__ V3 add_half(V3 x, V3 y) { return mk(fmaf(0.5f, y.x, x.x), fmaf(0.5f, y.y, x.y), fmaf(0.5f, y.z, x.z)); }
@@ -267,6 +269,19 @@ struct Shade {
     V3 accum;
     float alpha_total;
 };
+// A disk crossing waiting to be shaded.  Crossings of the lanes of a wave are spread over several
+// RK4 steps (measured: ~6 wave-steps per tile see a hit, each with a handful of live lanes), and
+// shading is ~700 instructions, so a hit is parked here and shaded together with the other lanes'
+// hits: when some lane needs its slot for the NEXT hit (front-to-back order is kept; that lane
+// repeats its step afterwards) or when the wave has finished marching.  Results are unchanged --
+// the same operations run later.
+template <bool DIFF>
+struct Pending {
+    float hit_x, hit_y;
+    V3 to_cam;
+    float dxx, dxy, dyx, dyy;   // DIFF only
+    int valid;
+};
 template <bool DIFF>
 __device__ __forceinline__ void shade_hit(const BhrMarchArgs &a, Shade &sh, float hit_x, float hit_y, V3 to_cam,
                                           float hdx_x, float hdx_y, float hdy_x, float hdy_y) {
@@ -354,6 +369,7 @@ struct Ray {
     float f_old;   // plane function at p
     float affine;
     Shade sh;
+    Pending<DIFF> pend;
     int step_count;
     int pix;       // linear pixel index inside the row block, -1 = lane has no ray
     int done;      // 0 running, 1 captured, 2 escaped, 3 ran out of iterations, 4 empty lane
@@ -373,6 +389,7 @@ struct Ray {
         affine = 0.0f;
         sh.accum = mk(0, 0, 0);
         sh.alpha_total = 0.0f;
+        pend.valid = 0;
         step_count = 0;
         done = a.max_iter <= 0 ? 3 : 0;
         esc = mk(0, 0, 0);
@@ -396,12 +413,13 @@ struct Ray {
                   div6(fmaf(2.0f, k3.z, fmaf(2.0f, k2.z, k1.z)) + k4.z));
     }
 
-    __device__ __forceinline__ void step(const BhrMarchArgs &a) {
+    // Returns false (nothing committed) when a hit finds the parking slot occupied; see the fast build.
+    __device__ __forceinline__ bool step(const BhrMarchArgs &a) {
         float r_safe = fmaxf(r, BHR_RS + 1e-3f);
         float far_scale = sqrt_rn(r_safe);               // sqrt(r_safe / r_cap), r_cap = 1
         if (far_scale > 10.0f) far_scale = 10.0f;
-        float q = div_rn(BHR_RS, r_safe);
-        float near_damp = div_rn(1.0f, 1.0f + 2.0f * (q * q * q));
+        float q = rcp_rn(r_safe);                        // r_cap / r_safe, r_cap = 1
+        float near_damp = rcp_rn(1.0f + 2.0f * (q * q * q));
         float dt_fac = far_scale * near_damp;
         if (dt_fac < 0.2f) dt_fac = 0.2f;
         if (dt_fac > 10.0f) dt_fac = 10.0f;
@@ -458,41 +476,47 @@ struct Ray {
 
         float r2n = dot(np, np);
         float rn = sqrt_rn(r2n);
-        affine += h;
+        float aff = affine + h;
         // termination precedes the plane test (render.py:2916-2926)
-        if (rn < BHR_RS) {
-            done = 1;
-            return;
-        }
-        if (rn > a.r_esc || affine > a.max_affine) {
-            done = 2;
-            esc = nd;
-            return;
-        }
-        if (DIFF) {
-            // committed BEFORE the hit interpolation (render.py:2928-2932), hence
-            // hit_d_pos == new_d_pos in render.py:2947-2949
-            dpx = ndpx; ddx = nddx; dpy = ndpy; ddy = nddy;
-        }
+        const bool captured = rn < BHR_RS;
+        const bool escaped = !captured && (rn > a.r_esc || aff > a.max_affine);
+        const bool alive = !captured && !escaped;
         float f_new = np.z - np.y * a.tan_t;
-        if (f_old * f_new < 0) {
-            float t_frac = f_old / (f_old - f_new + 1e-8f);
-            float hit_x = p.x + t_frac * (np.x - p.x);
-            float hit_y = p.y + t_frac * (np.y - p.y);
-            if (DIFF)
-                shade_hit<true>(a, sh, hit_x, hit_y, mk(-d.x, -d.y, -d.z), dpx.x, dpx.y, dpy.x, dpy.y);
-            else
-                shade_hit<false>(a, sh, hit_x, hit_y, mk(-d.x, -d.y, -d.z), 0, 0, 0, 0);
+        if (alive && f_old * f_new < 0) {
+            float t_frac = div_rn(f_old, f_old - f_new + 1e-8f);
+            float hx = p.x + t_frac * (np.x - p.x);
+            float hy = p.y + t_frac * (np.y - p.y);
+            float hit_r = sqrt_rn(hx * hx + hy * hy);
+            if (a.r_outer >= hit_r && hit_r >= a.r_inner) {   // render.py:2951
+                if (pend.valid) return false;                 // slot occupied: flush, then repeat this step
+                pend.valid = 1;
+                pend.hit_x = hx;
+                pend.hit_y = hy;
+                pend.to_cam = mk(-d.x, -d.y, -d.z);           // direction at the START of the step (render.py:2954)
+                // the differentials were committed BEFORE the hit interpolation (render.py:2928-2932),
+                // hence hit_d_pos == new_d_pos in render.py:2947-2949
+                if (DIFF) { pend.dxx = ndpx.x; pend.dxy = ndpx.y; pend.dyx = ndpy.x; pend.dyy = ndpy.y; }
+            }
         }
-        p = np;
-        d = nd;
-        r = rn;
-        r2p = r2n;
-        f_old = f_new;
-        step_count += 1;
-        if (step_count >= a.max_iter) done = 3;
+        affine = aff;
+        if (escaped) esc = nd;
+        if (alive) {
+            if (DIFF) { dpx = ndpx; ddx = nddx; dpy = ndpy; ddy = nddy; }
+            p = np;
+            d = nd;
+            r = rn;
+            r2p = r2n;
+            f_old = f_new;
+            step_count += 1;
+        }
+        done = captured ? 1 : (escaped ? 2 : (step_count >= a.max_iter ? 3 : 0));
+        return true;
     }
 
+    __device__ __forceinline__ void shade_pending(const BhrMarchArgs &a) {
+        shade_hit<DIFF>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
+        pend.valid = 0;
+    }
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, esc, sh); }
 };
 
@@ -521,6 +545,7 @@ struct Ray {
     V3 g1, g2;            // in-plane orthonormal basis
     float affine;
     Shade sh;
+    Pending<DIFF> pend;
     int step_count;
     int pix;
     int done;
@@ -567,6 +592,7 @@ struct Ray {
         affine = 0.0f;
         sh.accum = mk(0, 0, 0);
         sh.alpha_total = 0.0f;
+        pend.valid = 0;
         step_count = 0;
         done = a.max_iter <= 0 ? 3 : 0;
         pix = j_local * a.width + i;
@@ -609,8 +635,11 @@ struct Ray {
         return mk(fmaf(cu, g1.x, cw * g2.x), fmaf(cu, g1.y, cw * g2.y), fmaf(cu, g1.z, cw * g2.z));
     }
 
-    // One iteration of the while-loop at render.py:2854-3006.
-    __device__ __forceinline__ void step(const BhrMarchArgs &a) {
+    // One iteration of the while-loop at render.py:2854-3006.  Returns false when the step found a
+    // disk hit but the lane's parking slot still holds an unshaded earlier hit: nothing is committed,
+    // the wave shades its parked hits and the lane repeats the (deterministic) step.  Statement order
+    // keeps every state variable updated in place after its last use.
+    __device__ __forceinline__ bool step(const BhrMarchArgs &a) {
         // adaptive step (render.py:2858-2869) from 1/r:  q = 1/r_safe, sqrt(r_safe) = rsq(q)
         float q = fminf(ir, 1.0f / (BHR_RS + 1e-3f));
         float far_scale = fminf(q_rsq(q), 10.0f);
@@ -634,61 +663,74 @@ struct Ray {
         float s4u = fmaf(h, v3u, u), s4w = fmaf(h, v3w, w);
         float v4u = fmaf(h, a3u, du), v4w = fmaf(h, a3w, dw);
         float c4 = coef(s4u, s4w, i2_4);
-        float a4u = c4 * s4u, a4w = c4 * s4w;
         float nu = fmaf(h6, (du + v4u) + 2.0f * (v2u + v3u), u);
         float nw = fmaf(h6, (dw + v4w) + 2.0f * (v2w + v3w), w);
-        float ndu = fmaf(h6, (a1u + a4u) + 2.0f * (a2u + a3u), du);
-        float ndw = fmaf(h6, (a1w + a4w) + 2.0f * (a2w + a3w), dw);
+        float sdu = fmaf(c4, s4u, a1u) + 2.0f * (a2u + a3u);
+        float sdw = fmaf(c4, s4w, a1w) + 2.0f * (a2w + a3w);
 
         float r2n = fmaf(nu, nu, nw * nw);
-        affine += h;
+        float aff = affine + h;
         // termination precedes the plane test (render.py:2916-2926); r < 1  <=>  r^2 < 1 etc.
-        if (r2n < BHR_RS * BHR_RS) {
-            done = 1;
-            return;
+        const bool captured = r2n < BHR_RS * BHR_RS;
+        const bool escaped = !captured && (r2n > a.r_esc2 || aff > a.max_affine);
+        const bool alive = !captured && !escaped;
+        float f_new = Bn * nw;
+        bool redo = false;
+        if (alive && f_old * f_new < 0) {
+            float t_frac = f_old / (f_old - f_new + 1e-8f);
+            float hu = fmaf(t_frac, nu - u, u), hw = fmaf(t_frac, nw - w, w);
+            float hx = fmaf(hu, g1.x, hw * g2.x);
+            float hy = fmaf(hu, g1.y, hw * g2.y);
+            float hr2 = fmaf(hx, hx, hy * hy);
+            float hit_r = hr2 * q_rsq(hr2);
+            if (a.r_outer >= hit_r && hit_r >= a.r_inner) {   // render.py:2951
+                if (pend.valid) {
+                    redo = true;
+                } else {
+                    pend.valid = 1;
+                    pend.hit_x = hx;
+                    pend.hit_y = hy;
+                    V3 dir3 = to3d(du, dw);              // direction at the START of the step (render.py:2954)
+                    pend.to_cam = mk(-dir3.x, -dir3.y, -dir3.z);
+                }
+            }
         }
-        if (r2n > a.r_esc2 || affine > a.max_affine) {
-            done = 2;
-            du = ndu;   // escape direction = new_dir (render.py:2921)
-            dw = ndw;
-            return;
-        }
-        if (DIFF) {
-            // variational RK4 at the same four stage positions (render.py:2888-2911); committed
-            // before the hit test (render.py:2928-2932) so the hit sees the NEW differentials
+        if (redo) return false;
+        if (DIFF && alive) {
+            // variational RK4 at the same four stage positions (render.py:2888-2911); the hit reads the
+            // NEW differentials (committed before the plane test, render.py:2928-2932)
             float i2_1 = ir * ir;
             rk4_diff(dpx, ddx, h, hh, h6, s2u, s2w, s3u, s3w, s4u, s4w, c2, c3, c4, i2_1, i2_2, i2_3, i2_4);
             rk4_diff(dpy, ddy, h, hh, h6, s2u, s2w, s3u, s3w, s4u, s4w, c2, c3, c4, i2_1, i2_2, i2_3, i2_4);
-        }
-        float f_new = Bn * nw;
-        if (f_old * f_new < 0) {
-            float t_frac = f_old / (f_old - f_new + 1e-8f);
-            float hu = fmaf(t_frac, nu - u, u), hw = fmaf(t_frac, nw - w, w);
-            float hit_x = fmaf(hu, g1.x, hw * g2.x);
-            float hit_y = fmaf(hu, g1.y, hw * g2.y);
-            V3 dir3 = to3d(du, dw);
-            V3 to_cam = mk(-dir3.x, -dir3.y, -dir3.z);
-            if (DIFF) {
+            if (pend.valid == 1) {                       // hit parked in THIS step: attach its footprint
                 V3 e3 = cross(g1, g2);
-                shade_hit<true>(a, sh, hit_x, hit_y, to_cam,
-                                dpx.x * g1.x + dpx.y * g2.x + dpx.z * e3.x, dpx.x * g1.y + dpx.y * g2.y + dpx.z * e3.y,
-                                dpy.x * g1.x + dpy.y * g2.x + dpy.z * e3.x, dpy.x * g1.y + dpy.y * g2.y + dpy.z * e3.y);
-            } else {
-                shade_hit<false>(a, sh, hit_x, hit_y, to_cam, 0, 0, 0, 0);
+                pend.dxx = dpx.x * g1.x + dpx.y * g2.x + dpx.z * e3.x;
+                pend.dxy = dpx.x * g1.y + dpx.y * g2.y + dpx.z * e3.y;
+                pend.dyx = dpy.x * g1.x + dpy.y * g2.x + dpy.z * e3.x;
+                pend.dyy = dpy.x * g1.y + dpy.y * g2.y + dpy.z * e3.y;
             }
         }
-        u = nu;
-        w = nw;
-        du = ndu;
-        dw = ndw;
-        ir = q_rsq(r2n);
-        float i2 = ir * ir;
-        c1 = m15L2 * (i2 * i2 * ir);
-        f_old = f_new;
-        step_count += 1;
-        if (step_count >= a.max_iter) done = 3;
+        if (pend.valid == 1) pend.valid = 2;             // 1 = parked in this step, 2 = parked earlier
+        affine = aff;
+        du = fmaf(h6, sdu, du);                          // escaped rays read these back as the escape
+        dw = fmaf(h6, sdw, dw);                          // direction = new_dir (render.py:2921)
+        if (alive) {
+            u = nu;
+            w = nw;
+            ir = q_rsq(r2n);
+            float i2 = ir * ir;
+            c1 = m15L2 * (i2 * i2 * ir);
+            f_old = f_new;
+            step_count += 1;
+        }
+        done = captured ? 1 : (escaped ? 2 : (step_count >= a.max_iter ? 3 : 0));
+        return true;
     }
 
+    __device__ __forceinline__ void shade_pending(const BhrMarchArgs &a) {
+        shade_hit<DIFF>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
+        pend.valid = 0;
+    }
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, to3d(du, dw), sh); }
 };
 #endif  // BHR_MARCH_STRICT
@@ -710,25 +752,30 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 template <bool DIFF>
 __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int b = blockIdx.x;
-    const int bx_n = (a.width + 31) / 32;
-    const int bx = b % bx_n, by = b / bx_n;
-    const int i = bx * 32 + wave * 8 + (lane & 7);
-    const int j = by * 8 + (lane >> 3);
-    const bool valid = i < a.width && j < a.rows;
+    // one 8x8 tile per wave, tiles in row-major order; blockDim.x / 64 waves per block
+    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int i = tx * 8 + (lane & 7);
+    const int j = ty * 8 + (lane >> 3);
+    const bool valid = tile < a.n_tiles && i < a.width && j < a.rows;
 
     Ray<DIFF> ray;
     ray.init(a, valid ? i : 0, valid ? j : 0);
     if (!valid) ray.done = 4;
     unsigned int executed = 0;
-    // wave-level exit: keep stepping while __ballot reports a live lane
-    while (__ballot(ray.done == 0)) {
-        if (ray.done == 0) {
-            ray.step(a);
-            executed++;
+    // Divergent loop: a lane leaves when its ray terminates, the wave leaves when its EXEC mask is
+    // empty (the hardware form of "loop while __ballot(alive)").  Written without an inner `if` because
+    // hipcc otherwise shuttles the whole ray state through v_mov at every iteration (24 moves/step).
+    while (ray.done == 0) {
+        const bool blocked = !ray.step(a);
+        executed += blocked ? 0u : 1u;
+        // some live lane found its parking slot occupied: the live lanes shade what they have parked,
+        // that lane then repeats its step
+        if (__ballot(blocked)) {
+            if (ray.pend.valid) ray.shade_pending(a);
         }
     }
+    if (ray.pend.valid) ray.shade_pending(a);
     if (valid) ray.finish(a);
     unsigned long long tot = wave_sum_u32(executed);
     if (lane == 0) atomicAdd(a.ray_steps, tot);
@@ -763,6 +810,7 @@ __global__ __launch_bounds__(256) void march_persistent_kernel(BhrMarchArgs a, i
         int n_live = __popcll(live);
         if (!queue_empty && n_live < refill_below) {
             // retire finished lanes, then hand every non-running lane a new pixel
+            if (ray.pend.valid && ray.done != 0) ray.shade_pending(a);
             if (ray.done >= 1 && ray.done <= 3) ray.finish(a);
             unsigned long long want = ~live;
             int n_want = 64 - n_live;
@@ -783,12 +831,17 @@ __global__ __launch_bounds__(256) void march_persistent_kernel(BhrMarchArgs a, i
             continue;
         }
         if (!live) {
+            if (ray.pend.valid) ray.shade_pending(a);
             if (ray.done >= 1 && ray.done <= 3) ray.finish(a);
             break;
         }
+        bool blocked = false;
         if (ray.done == 0) {
-            ray.step(a);
-            executed++;
+            blocked = !ray.step(a);
+            executed += blocked ? 0u : 1u;
+        }
+        if (__ballot(blocked)) {
+            if (ray.pend.valid) ray.shade_pending(a);
         }
     }
     unsigned long long tot = wave_sum_u32(executed);
@@ -801,13 +854,15 @@ __device__ __forceinline__ unsigned int lcg(unsigned int &s) { s = s * 1664525u 
 __global__ void selftest_kernel(unsigned long long *out, unsigned int div_rounds) {
     const unsigned int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     unsigned long long bad_sqrt = 0, bad_div = 0, bad_div6 = 0, n = 0;
-    // every f32 in [2^-40, 2^40): exponent field 87..166, all significands
-    for (unsigned long long k = tid; k < 80ull << 23; k += nthreads) {
-        float x = __uint_as_float((unsigned int)(k + (87ull << 23)));
+    // every f32 in [2^-80, 2^80): exponent field 47..206, all significands
+    for (unsigned long long k = tid; k < 160ull << 23; k += nthreads) {
+        float x = __uint_as_float((unsigned int)(k + (47ull << 23)));
         bad_sqrt += sqrt_rn(x) != sqrtf(x);
+        bad_div += rcp_rn(x) != 1.0f / x;
+        bad_div += rcp_rn(-x) != 1.0f / -x;
         bad_div6 += div6(x) != x / 6.0f;
         bad_div6 += div6(-x) != -x / 6.0f;
-        n += 3;
+        n += 5;
     }
     // random pairs: a, b with exponents in [2^-24, 2^24), random significands and signs
     unsigned int st = tid * 2654435761u + 12345u;
@@ -921,8 +976,13 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     BHR_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (slot >= 0) BHR_HIP(hipEventRecord(ctx->ring_ev[slot * 3 + 0], ctx->stream));
     if (!(flags & BHR_PERSISTENT)) {
-        const int bx_n = (c.width + 31) / 32, by_n = (ctx->rows + 7) / 8;
-        dim3 grid(bx_n * by_n), block(256);
+        // waves per block: a block keeps its CU slot until its slowest wave has finished, so small
+        // blocks shorten the tail; BHR_TILE_BLOCK overrides for experiments
+        int bt = 256;
+        if (const char *e = getenv("BHR_TILE_BLOCK")) bt = atoi(e);
+        if (bt != 64 && bt != 128 && bt != 256) bt = 256;
+        const int wpb = bt / 64;
+        dim3 grid((a.n_tiles + wpb - 1) / wpb), block(bt);
         if (want_diff)
             hipLaunchKernelGGL(march_tile_kernel<true>, grid, block, 0, ctx->stream, a);
         else

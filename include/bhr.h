@@ -182,8 +182,8 @@ BHR_API int32_t bhr_read_layer(bhr_ctx *ctx, int32_t layer, float *out);
 BHR_API int32_t bhr_read_final_u8(bhr_ctx *ctx, uint8_t *out);
 BHR_API int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out);
 /* Device self-test of the strict march's hand-written exact sqrt / divide / divide-by-6 against the
- * compiler's IEEE sequences: out[0..2] = mismatches (sqrt over every f32 in [2^-40, 2^40), divide
- * over 2^30 random pairs, x/6 over the same range as sqrt), out[3] = comparisons made. */
+ * compiler's IEEE sequences: out[0..2] = mismatches (sqrt over every f32 in [2^-80, 2^80); 1/x over
+ * the same range plus a/b over 2^30 random pairs; x/6 over the same range), out[3] = comparisons made. */
 BHR_API int32_t bhr_selftest(bhr_ctx *ctx, uint64_t out[4]);
 /* forget the per-frame timing ring (call before a timed region) */
 BHR_API int32_t bhr_timing_reset(bhr_ctx *ctx);
