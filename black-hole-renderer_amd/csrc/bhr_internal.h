@@ -6,6 +6,7 @@
 
 #include "../../include/bhr.h"
 #include "../../include/bhr_disk_v2.h"
+#include "../../include/bhr_lifecycle.h"
 
 #define BHR_NUM_MIP_LEVELS 5  // generate_disk_mipmaps(levels=4) => 5 stored levels (render.py:2239-2240)
 #define BHR_WAVE 64
@@ -84,6 +85,14 @@ struct bhr_ctx {
     float stats[2];
     float *d_noise_in, *d_noise_out;
     int64_t noise_cap;
+    // device lifecycle (lifecycle.hip)
+    float *d_pool;             // entity profile pool (bump allocated)
+    int64_t pool_used, pool_cap;
+    void *d_pairs;             // per-call pair tables
+    size_t pairs_cap;
+    float *d_stats_scratch;    // density | temp_struct | histogram | row results
+    size_t stats_scratch_elems;
+    int32_t stats_prepared;
 
     // frame buffers for rows [row0,row1)
     float *d_bg, *d_disk;      // (rows, W, 3)

@@ -1,0 +1,224 @@
+"""Device-side entity layer and compose statistics (include/bhr_lifecycle.h).
+
+The host keeps what is cheap and order-sensitive -- the factories' random streams, the per-entity
+scalars, the per-(entity, row) scalars that depend on NumPy's promotion rules -- and hands the
+per-texel work to the GPU: ~12 000 (entity, row) pairs instead of 6 x n_r x n_phi texels cross
+PCIe per frame, and the percentile statistics are selected on the device without reading the 13
+component planes back.  `lifecycle.rasterize_entities` / `compose_statistics` remain the
+reference-identical host implementations these are tested against.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from .lifecycle import (FILAMENT_BIRTH_FADE_DUR, FILAMENT_DEATH_THRESHOLD)
+
+FIL_DTYPE = np.dtype([("center", "<f8"), ("inv_2s_phi", "<f8"), ("coef_d", "<f8"), ("coef_t", "<f8")])
+ROL_DTYPE = np.dtype([("offset", "<i8"), ("shift", "<i4"), ("plane", "<i4"), ("alpha", "<f4"), ("stride", "<i4")])
+_PLANE = {"rt_spike": 2, "hotspot": 4}
+_TWO_PI = 2 * np.pi
+
+
+def _bind(lib):
+    if getattr(lib, "_lifecycle_typed", False):
+        return
+    P, I32, I64 = C.c_void_p, C.c_int32, C.c_int64
+    F, D = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    lib.bhr_entity_profile_upload.argtypes = [P, F, F, I32, C.POINTER(I64)]
+    lib.bhr_entity_profile_reset.argtypes = [P]
+    lib.bhr_accumulate_entities.argtypes = [P, P, C.POINTER(I32), P, C.POINTER(I32), D]
+    lib.bhr_stats_prepare.argtypes = [P, I32, C.POINTER(C.c_uint64)]
+    lib.bhr_stats_select.argtypes = [P, I32, C.c_uint64, F]
+    lib.bhr_stats_row_statistics.argtypes = [P, C.c_float, I32, I32, F]
+    for n in ("bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities",
+              "bhr_stats_prepare", "bhr_stats_select", "bhr_stats_row_statistics"):
+        getattr(lib, n).restype = I32
+    lib._lifecycle_typed = True
+
+
+# --------------------------------------------------------------------------- pair tables
+def filament_pairs(factory, now: float, n_r: int, omega_rows: np.ndarray, r_norm_all: np.ndarray):
+    """(rows, table) for the alive filaments in list order (render.py:3606-3638).  The per-row
+    scalars are evaluated exactly as `lifecycle.rasterize_entities` does (f32 centre under NumPy's
+    weak-scalar promotion, f64 radial weight through math.exp)."""
+    rows_all, recs = [], []
+    two_pi32 = np.float32(_TWO_PI)
+    for e in factory.alive_entities:
+        age = now - e.birth_time
+        if e.density_factor(age) < FILAMENT_DEATH_THRESHOLD:
+            continue
+        s0 = max(e.blob_sigma_phi0, 1e-6)
+        sigma_phi = s0 + e.alpha_shear * age
+        amp_d = e.blob_peak_density * s0 / sigma_phi
+        amp_t = e.blob_peak_temp * s0 / sigma_phi
+        born = min(age / FILAMENT_BIRTH_FADE_DUR, 1.0) if FILAMENT_BIRTH_FADE_DUR > 0 else 1.0
+        cool = math.exp(-age / e.tau_cool) if e.tau_cool > 0 else 1.0
+        scale_d = amp_d * born * cool
+        scale_t = amp_t * born * cool
+        inv_2s_phi = 0.5 / (sigma_phi * sigma_phi)
+        sigma_r = max(e.blob_sigma_r, 1e-6)
+        inv_2s_r = 0.5 / (sigma_r * sigma_r)
+        rows = e.row_indices[(e.row_indices >= 0) & (e.row_indices < n_r)]
+        if len(rows) == 0:
+            continue
+        r_w = np.array([math.exp(-(r_norm_all[ri] - e.blob_base_r) ** 2 * inv_2s_r) for ri in rows])
+        center = (np.float32(e.source_phi) - omega_rows[rows] * np.float32(age)) % two_pi32   # f32, as the scalar code
+        rec = np.empty(len(rows), dtype=FIL_DTYPE)
+        rec["center"] = center.astype(np.float64)
+        rec["inv_2s_phi"] = inv_2s_phi
+        rec["coef_d"] = scale_d * r_w
+        rec["coef_t"] = scale_t * r_w
+        rows_all.append(rows)
+        recs.append(rec)
+    if not recs:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=FIL_DTYPE)
+    return np.concatenate(rows_all).astype(np.int64), np.concatenate(recs)
+
+
+def rolled_pairs(factories: dict, now: float, n_r: int, n_phi: int, omega_rows: np.ndarray, pool):
+    """(rows, table) for RT spikes then hotspots (render.py:3640-3649)."""
+    rows_all, recs = [], []
+    for key in ("rt_spike", "hotspot"):
+        factory = factories.get(key)
+        if factory is None:
+            continue
+        for e in factory.alive_entities:
+            alpha = e.fade_factor(now)
+            if alpha <= 0:
+                continue
+            age = now - e.birth_time
+            off, stride = pool.offset_of(e)
+            k_idx = np.nonzero((e.row_indices >= 0) & (e.row_indices < n_r))[0]
+            rows = e.row_indices[k_idx]
+            if len(rows) == 0:
+                continue
+            # int(age * omega[row] / (2 pi) * n_phi) with the f32 arithmetic of np.float32 scalars
+            shift = (np.float32(age) * omega_rows[rows] / np.float32(_TWO_PI) * np.float32(n_phi)).astype(np.int64)
+            rec = np.empty(len(rows), dtype=ROL_DTYPE)
+            rec["offset"] = off + k_idx.astype(np.int64) * n_phi
+            rec["shift"] = shift
+            rec["plane"] = _PLANE[key]
+            rec["alpha"] = np.float32(alpha)
+            rec["stride"] = stride
+            rows_all.append(rows)
+            recs.append(rec)
+    if not recs:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=ROL_DTYPE)
+    return np.concatenate(rows_all).astype(np.int64), np.concatenate(recs)
+
+
+def to_csr(rows: np.ndarray, table: np.ndarray, n_r: int):
+    """Group by texture row, keeping the visiting order inside each row (stable sort)."""
+    order = np.argsort(rows, kind="stable")
+    ptr = np.searchsorted(rows[order], np.arange(n_r + 1)).astype(np.int32)
+    return np.ascontiguousarray(table[order]), ptr
+
+
+class ProfilePool:
+    """Device copies of the pre-rasterised hotspot / RT-spike rows, uploaded once per entity."""
+
+    def __init__(self, lib, ctx, n_phi: int):
+        self.lib, self.ctx, self.n_phi = lib, ctx, n_phi
+        self._live = {}
+
+    def offset_of(self, e):
+        key = id(e)
+        hit = self._live.get(key)
+        if hit is not None and hit[2] is e:
+            return hit[0], hit[1]
+        dens = np.ascontiguousarray(e.phi_density, dtype=np.float32)
+        temp = np.ascontiguousarray(e.phi_temp, dtype=np.float32)
+        off = C.c_int64()
+        _lib.check(self.lib.bhr_entity_profile_upload(self.ctx, _lib.fptr(dens), _lib.fptr(temp), dens.shape[0],
+                                                      C.byref(off)))
+        self._live[key] = (int(off.value), dens.shape[0] * self.n_phi, e)
+        return self._live[key][0], self._live[key][1]
+
+    def collect(self, factories: dict) -> None:
+        """Forget dead entities; rebuild the pool when three quarters of it is garbage."""
+        alive = {id(e) for k in ("rt_spike", "hotspot") if k in factories for e in factories[k].alive_entities}
+        dead = [k for k in self._live if k not in alive]
+        for k in dead:
+            del self._live[k]
+        self._dead_since_reset = getattr(self, "_dead_since_reset", 0) + len(dead)
+        if self._dead_since_reset > 3 * max(len(alive), 1):
+            _lib.check(self.lib.bhr_entity_profile_reset(self.ctx))
+            self._live.clear()
+            self._dead_since_reset = 0
+
+
+def accumulate_on_device(lib, ctx, pool: ProfilePool, factories: dict, now: float, n_r: int, n_phi: int,
+                         omega_rows: np.ndarray, r_norm_all: np.ndarray) -> None:
+    _bind(lib)
+    pool.collect(factories)
+    fil = factories.get("filament")
+    f_rows, f_tab = filament_pairs(fil, now, n_r, omega_rows, r_norm_all) if fil is not None else (
+        np.zeros(0, np.int64), np.zeros(0, FIL_DTYPE))
+    r_rows, r_tab = rolled_pairs(factories, now, n_r, n_phi, omega_rows, pool)
+    f_tab, f_ptr = to_csr(f_rows, f_tab, n_r)
+    r_tab, r_ptr = to_csr(r_rows, r_tab, n_r)
+    phi = np.linspace(0, 2 * np.pi, n_phi, endpoint=False)
+    i32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    _lib.check(lib.bhr_accumulate_entities(
+        ctx, f_tab.ctypes.data_as(C.c_void_p) if len(f_tab) else None, i32p(f_ptr),
+        r_tab.ctypes.data_as(C.c_void_p) if len(r_tab) else None, i32p(r_ptr),
+        phi.ctypes.data_as(C.POINTER(C.c_double))))
+
+
+# --------------------------------------------------------------------------- statistics
+# NumPy 2.x evaluates quantiles of f32 data in f32: q is cast to the array dtype, the virtual index
+# (n - 1) q and the interpolation weight are f32, and so is the lerp (numpy/lib/_function_base_impl.py:
+# quantile/percentile, _compute_virtual_index, _get_gamma, _lerp).  The device only selects order
+# statistics; these helpers reproduce the index and lerp arithmetic, and
+# tests/test_golden_host.py::test_numpy_lerp_replicates_percentile_and_quantile pins them to the
+# installed NumPy.
+def linear_rank(n: int, q32: np.float32):
+    """(lo, hi, gamma) of method='linear' for n samples and an f32 quantile."""
+    vi = (n - 1) * q32                                   # python int * np.float32 -> f32
+    lo = int(np.floor(vi))
+    hi = min(lo + 1, n - 1)
+    gamma = np.float32(np.float64(vi) - lo)              # f32 - intp -> f64, cast back to the index dtype
+    return lo, hi, gamma
+
+
+def percentile_q(p: float) -> np.float32:
+    """np.percentile(f32 array, p): q = p / f32(100)."""
+    return np.true_divide(p, np.float32(100))
+
+
+def numpy_lerp(a, b, t) -> np.float32:
+    a, b, t = np.float32(a), np.float32(b), np.float32(t)
+    diff = np.subtract(b, a)
+    if t >= 0.5:
+        return np.float32(b - diff * (1 - t))
+    return np.float32(a + diff * t)
+
+
+def stats_on_device(lib, ctx, n_r: int, n_phi: int, enable_rt: int):
+    """(density_p98, struct_scale, row_stats) as compose_statistics returns them, selected on the device."""
+    _bind(lib)
+    n_pos = C.c_uint64()
+    _lib.check(lib.bhr_stats_prepare(ctx, int(bool(enable_rt)), C.byref(n_pos)))
+
+    def select(which, n, q32):
+        lo, hi, g = linear_rank(n, q32)
+        a, b = C.c_float(), C.c_float()
+        _lib.check(lib.bhr_stats_select(ctx, which, lo, C.byref(a)))
+        _lib.check(lib.bhr_stats_select(ctx, which, hi, C.byref(b)))
+        return float(numpy_lerp(a.value, b.value, g))
+
+    density_p98 = max(select(0, n_r * n_phi, percentile_q(98)), 0.01)
+    struct_scale = select(1, int(n_pos.value), percentile_q(95)) if n_pos.value > 0 else 1.0
+    struct_scale = max(struct_scale, 0.01)
+    rows = np.empty((n_r, 4), dtype=np.float32)
+    div = np.float32(struct_scale + 1e-6)          # temp_struct / (struct_scale + 1e-6): weak python scalar -> f32
+    lo, hi, g = linear_rank(n_phi, np.float32(0.7))
+    _lib.check(lib.bhr_stats_row_statistics(ctx, float(div), lo, hi, _lib.fptr(rows)))
+    row_p70 = np.array([numpy_lerp(a, b, g) for a, b in zip(rows[:, 1], rows[:, 2])], dtype=np.float32)
+    row_max = np.maximum(rows[:, 0], rows[:, 3])
+    row_p70 = np.maximum(row_p70, rows[:, 3] * 0.8)
+    return density_p98, struct_scale, np.column_stack([row_max, row_p70]).astype(np.float32)

@@ -192,6 +192,7 @@ class HipRenderer:
                                          _lib.fptr(edge), _lib.fptr(omega_rows)))
         self._bg_omega_all_np = omega_rows
         self._bg_r_norm_all = np.linspace(0, 1, n_r)
+        self._profile_pool = None
         self._bg_n_r, self._bg_n_phi = n_r, n_phi
         self._install_field_views(n_r, n_phi, edge, omega_rows)
         tb_init = np.clip(1.0 - np.linspace(0, 1, n_r), 0, 1) ** 1.3 * 0.25
@@ -226,9 +227,20 @@ class HipRenderer:
         _lib.check(self._lib.bhr_read_comp(self._ctx, _lib.fptr(out)))
         return out
 
+    # The entity layer and the statistics run on the device by default (lifecycle_device.py);
+    # device_lifecycle = False selects the reference-identical NumPy implementations + upload,
+    # which the GPU tests compare against.
+    device_lifecycle = True
+
     def accumulate_entity_layer(self, factories: dict, now: float) -> None:
-        """Rasterise the alive entities into staging (6, n_r, n_phi) and upload it to comp[5:11]
-        (render.py:3564-3653)."""
+        """Rasterise the alive entities into comp[5:11] (render.py:3564-3653)."""
+        if self.device_lifecycle:
+            from . import lifecycle_device as ld
+            if getattr(self, "_profile_pool", None) is None:
+                self._profile_pool = ld.ProfilePool(self._lib, self._ctx, self._bg_n_phi)
+            ld.accumulate_on_device(self._lib, self._ctx, self._profile_pool, factories, now, self._bg_n_r,
+                                    self._bg_n_phi, self._bg_omega_all_np, self._bg_r_norm_all)
+            return
         from .lifecycle import rasterize_entities
         staging = rasterize_entities(factories, now, self._bg_n_r, self._bg_n_phi, self._bg_omega_all_np,
                                      self._bg_r_norm_all)
@@ -236,8 +248,13 @@ class HipRenderer:
 
     def recompute_interactive_stats(self) -> None:
         """Normalisation statistics from the current components (render.py:3655-3712)."""
-        from .lifecycle import compose_statistics
-        p98, scale, row_stats = compose_statistics(self.read_comp(), self._edge_np, self._param_enable_rt)
+        if self.device_lifecycle and self._bg_n_phi <= 32768:
+            from . import lifecycle_device as ld
+            p98, scale, row_stats = ld.stats_on_device(self._lib, self._ctx, self._bg_n_r, self._bg_n_phi,
+                                                       self._param_enable_rt)
+        else:
+            from .lifecycle import compose_statistics
+            p98, scale, row_stats = compose_statistics(self.read_comp(), self._edge_np, self._param_enable_rt)
         self._set_stats(p98, scale, row_stats)
 
     def compose_interactive_texture(self, solo_idx: int = -1) -> None:

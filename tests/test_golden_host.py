@@ -127,3 +127,25 @@ def test_lens_flare():
     np.testing.assert_array_equal(out.transpose(1, 0, 2), d["flare_out"])
     dark = apply_lens_flare(final, np.zeros_like(disk))                  # early-out: no disk light
     np.testing.assert_array_equal(dark.transpose(1, 0, 2), d["flare_dark_out"])
+
+
+def test_numpy_lerp_replicates_percentile_and_quantile():
+    """lifecycle_device.linear_rank / numpy_lerp + the two neighbouring order statistics give exactly what
+    np.percentile / np.quantile return on f32 data (the device only selects order statistics)."""
+    from bhr_amd.lifecycle_device import linear_rank, numpy_lerp, percentile_q
+    rng = np.random.default_rng(3)
+    for n in (7, 100, 2912, 11632, 100003, 1211392):
+        x = (rng.random(n, dtype=np.float32) ** 3).astype(np.float32)
+        srt = np.sort(x)
+        for p in (98, 95, 50):
+            lo, hi, g = linear_rank(n, percentile_q(p))
+            got = numpy_lerp(srt[lo], srt[hi], g)
+            want = np.percentile(x, p)
+            assert got == want and type(want) == np.float32, (n, p, got, want)
+        lo, hi, g = linear_rank(n, np.float32(0.7))
+        assert numpy_lerp(srt[lo], srt[hi], g) == np.quantile(x, 0.7)
+    m = rng.random((5, 2912), dtype=np.float32)
+    s = np.sort(m, axis=1)
+    lo, hi, g = linear_rank(2912, np.float32(0.7))
+    got = np.array([numpy_lerp(r[lo], r[hi], g) for r in s], dtype=np.float32)
+    np.testing.assert_array_equal(got, np.quantile(m, 0.7, axis=1).astype(np.float32))

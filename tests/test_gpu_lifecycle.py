@@ -1,0 +1,101 @@
+"""Device entity layer + statistics (include/bhr_lifecycle.h) against the reference-identical NumPy
+implementations (bhr_amd.lifecycle, themselves pinned bit-for-bit by tests/golden/lifecycle.npz)."""
+import numpy as np
+import pytest
+
+from bhr_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _renderer(n_r, n_phi, **kw):
+    from bhr_amd import HipRenderer
+    return HipRenderer(64, 36, scenes.analytic_skybox(32, 64), np.zeros((n_r, n_phi, 4), dtype=np.float32),
+                       r_disk_inner=2.0, r_disk_outer=15.0, **kw)
+
+
+@pytest.mark.parametrize("n_r,n_phi", [(48, 96), (128, 336), (416, 2912)])
+def test_entity_layer_matches_host_rasteriser(hip_lib, n_r, n_phi):
+    from bhr_amd.lifecycle import make_factories, rasterize_entities
+    r = _renderer(n_r, n_phi)
+    r.init_background_layer(n_r, n_phi, seed=42)
+    fac = make_factories(n_r, n_phi, 2.0, 15.0, seed=42)
+    now = 0.0
+    for step in range(0, 241, 60):                      # t = 0, 6, 12, 18, 24 s: births, deaths, fades
+        while now < step * 0.1 - 1e-9:
+            now += 0.1
+            for f in fac.values():
+                f.tick(now=now, dt=0.1)
+        want = rasterize_entities(fac, now, n_r, n_phi, r._bg_omega_all_np, r._bg_r_norm_all)
+        r.accumulate_entity_layer(fac, now)             # device path (default)
+        got = r.read_comp()[5:11]
+        # hotspots / RT spikes: f32 roll-scale-accumulate in the reference's order -> bit-exact
+        np.testing.assert_array_equal(got[2:6], want[2:6])
+        # filaments: binary64 Gaussian, ocml exp vs NumPy's exp (<= 1 ulp of f64 before the f32 rounding)
+        np.testing.assert_allclose(got[0:2], want[0:2], rtol=0, atol=1e-7)
+        assert (got[0:2] != want[0:2]).mean() < 1e-3
+        assert want[0].max() > 0.1 and want[2].max() > 0.1 and want[4].max() > 0.1
+    r.close()
+
+
+def test_profile_pool_survives_turnover(hip_lib):
+    """Many ticks: entities die and spawn, the pool is rebuilt; results stay equal to the host path."""
+    from bhr_amd.lifecycle import make_factories, rasterize_entities
+    n_r, n_phi = 48, 96
+    r = _renderer(n_r, n_phi)
+    r.init_background_layer(n_r, n_phi, seed=42)
+    fac = make_factories(n_r, n_phi, 2.0, 15.0, seed=42)
+    for k in range(1, 1501):
+        now = k * 0.1
+        for f in fac.values():
+            f.tick(now=now, dt=0.1)
+        if k % 100 == 0:
+            r.accumulate_entity_layer(fac, now)
+            want = rasterize_entities(fac, now, n_r, n_phi, r._bg_omega_all_np, r._bg_r_norm_all)
+            got = r.read_comp()[5:11]
+            np.testing.assert_array_equal(got[2:6], want[2:6])
+            np.testing.assert_allclose(got[0:2], want[0:2], rtol=0, atol=1e-7)
+    r.close()
+
+
+@pytest.mark.parametrize("n_r,n_phi", [(48, 96), (416, 2912)])
+def test_statistics_match_numpy_exactly(hip_lib, n_r, n_phi):
+    from bhr_amd.lifecycle import compose_statistics, make_factories, rasterize_entities
+    r = _renderer(n_r, n_phi)
+    r.init_background_layer(n_r, n_phi, seed=42)
+    fac = make_factories(n_r, n_phi, 2.0, 15.0, seed=42)
+    r.generate_background(3.0)
+    r.device_lifecycle = False                           # upload the host staging: identical comp on both sides
+    r.accumulate_entity_layer(fac, 0.0)
+    comp = r.read_comp()
+    want = compose_statistics(comp, r._edge_np, 1)
+    r.device_lifecycle = True
+    r.recompute_interactive_stats()
+    assert np.float32(want[0]) == r._stats_np[0] and np.float32(want[1]) == r._stats_np[1]
+    np.testing.assert_array_equal(r._row_stats_np, want[2])
+    # degenerate input: no positive structural temperature -> struct_scale falls back to 1.0 -> floor 0.01 rule
+    import bhr_amd._lib as L
+    z = np.zeros_like(comp)
+    z[12] = 1.0
+    L.check(r._lib.bhr_set_comp(r._ctx, L.fptr(z)))
+    r.recompute_interactive_stats()
+    w = compose_statistics(z, r._edge_np, 1)
+    assert np.float32(w[0]) == r._stats_np[0] and np.float32(w[1]) == r._stats_np[1]
+    np.testing.assert_array_equal(r._row_stats_np, w[2])
+    r.close()
+
+
+def test_device_and_host_lifecycle_render_the_same_frame(hip_lib):
+    from bhr_amd import HipRenderer
+    from bhr_amd.drivers import advance_lifecycle_frame, init_lifecycle_system
+    imgs = []
+    for dev in (True, False):
+        r = HipRenderer(320, 180, scenes.analytic_skybox(64, 128), np.zeros((128, 336, 4), dtype=np.float32),
+                        r_disk_inner=2.0, r_disk_outer=3.5, disk_tilt=15.0)
+        r.device_lifecycle = dev
+        fac = init_lifecycle_system(r, 128, 336, seed=42)
+        for k in range(1, 4):
+            advance_lifecycle_frame(r, fac, t=0.1 * k, dt=0.1, recompute_stats=(k == 3))
+        imgs.append(r.render([6, 0, 0.5], 60))
+        r.close()
+    assert np.abs(imgs[0] - imgs[1]).max() < 2e-5
