@@ -165,6 +165,7 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     if ((rc = dev_alloc(&ctx->d_final_u8, px3))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_hblur, 3 * (rows + 2 * R) * W))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_wtab, 3 * (R + 1 + 64)))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_wext, 3 * (2 * (R + 4) + 8)))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_wsum_h, 3 * W))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_wsum_v, 3 * H))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_ray_steps, 1))) return bail(rc);
@@ -194,7 +195,7 @@ void bhr_destroy(bhr_ctx *ctx) {
     free_bg(ctx);
     void *bufs[] = {ctx->d_skybox, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_final_u8, ctx->d_hblur,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_queue, ctx->d_noise_in,
-                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch};
+                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

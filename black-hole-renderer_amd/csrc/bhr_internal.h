@@ -101,6 +101,7 @@ struct bhr_ctx {
     float *d_final;            // (rows, W, 3)
     uint8_t *d_final_u8;       // (rows, W, 3)
     float *d_wtab;             // bloom weights (3, R + pad)
+    float *d_wext;             // unfolded weights (3, 2 R4 + 8)
     float *d_wsum_h;           // (3, W)
     float *d_wsum_v;           // (3, H)
     int32_t bloom_R, bloom_ready;

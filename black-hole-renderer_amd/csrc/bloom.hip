@@ -1,30 +1,36 @@
 // bloom.hip -- separable RGB-dispersion bloom + final combine for gfx950.
 //
-// Restates _bloom_kernel (render.py:3022-3114) as the reference's render()
-// drives it (render.py:3914-3918): threshold 0, radius R = int(0.02 W), weights
-// exp(-d^2 / (sigma_c * s)) with sigma = {25, 80, 1600} per channel and
-// s = (W/640)^2, out-of-image taps skipped and every channel divided by its own
-// in-bounds weight sum.  With threshold 0 and a non-negative disk layer the
-// "bright" copy equals the disk layer (lum > 0 fails only for all-zero pixels),
-// so pass 1 of the reference is folded away.
+// Restates _bloom_kernel (render.py:3022-3114) as the reference's render() drives it
+// (render.py:3914-3918): threshold 0, radius R = int(0.02 W), weights exp(-d^2 / (sigma_c * s)) with
+// sigma = {25, 80, 1600} per channel and s = (W/640)^2, out-of-image taps skipped and every channel
+// divided by its own in-bounds weight sum.  With threshold 0 and a non-negative disk layer the
+// "bright" copy equals the disk layer (lum > 0 fails only for all-zero pixels), so pass 1 of the
+// reference is folded away.
 //
-//   H pass : (rows, W, 3) disk layer -> planar (3, rows + 2R, W) intermediate,
-//            one 256-pixel row segment (+2R halo) staged through LDS per block;
-//   V pass : thread per column, TY output rows per thread in registers,
-//            coalesced row reads; epilogue fuses clip(bg + disk + blur) of
-//            render.py:3918 and writes the (rows, W, 3) final image.
-// The intermediate carries R halo rows on either side so that row-block tiles
-// on different GPUs can exchange them (bhr_group_render).
+// Both passes are FMA bound ((2R + 1) x 3 FMAs per pixel per pass: 77 taps at fhd, 307 at 8k), so
+// the kernels are built to issue almost nothing else:
+//   * every thread produces 4 adjacent outputs from a window staged in LDS and read with 16-byte
+//     ds_read_b128 (1 LDS read per 16 FMAs);
+//   * tap weights are uniform across the wave: they are fetched with scalar loads into SGPRs and
+//     used as the scalar operand of v_fma, never through VGPRs or LDS;
+//   * H pass: (rows, W, 3) disk layer -> planar (3, rows + 2R, W) intermediate, 1024 pixels of one row
+//     per block; V pass: 32 columns x 128 rows per block, the tile transposed in LDS so that the
+//     vertical window is contiguous, epilogue fuses clip(bg + disk + blur) of render.py:3918.
+// The intermediate carries R halo rows on either side so that row-block tiles on different GPUs can
+// exchange them (bhr_group_render).  Summation order differs from the reference's tap order
+// (-R .. R) only by f32 rounding (tests: 2e-6 against the oracle's bloom).
 #include "bhr_internal.h"
 
 namespace {
 
-constexpr int HB = 256;  // pixels per H-pass block
-constexpr int TY = 8;    // output rows per V-pass thread
+constexpr int WPAD = 8;       // zero entries behind w[R] in the weight table (window overhang <= 6)
+constexpr int HB_PIX = 1024;  // pixels per H-pass block (256 threads x 4)
+constexpr int VB_COLS = 32;   // columns per V-pass block
+constexpr int VB_ROWS = 128;  // output rows per V-pass block (8 row-lanes x 4 groups x 4 rows)
 
-__global__ void bloom_weights_kernel(float *wtab, int R, int pad, float sigma_scale) {
+__global__ void bloom_weights_kernel(float *wtab, int R, float sigma_scale) {
     int d = blockIdx.x * blockDim.x + threadIdx.x;
-    int n = R + 1 + pad;
+    int n = R + 1 + WPAD;
     if (d >= n) return;
     float dist_sq = (float)(d * d);
     bool in = d <= R;
@@ -33,11 +39,21 @@ __global__ void bloom_weights_kernel(float *wtab, int R, int pad, float sigma_sc
     wtab[2 * n + d] = in ? expf(-dist_sq / (1600.0f * sigma_scale)) : 0.0f;
 }
 
+// wext[c][i] = w_c[|i - (R4 + 3)|], i < 2 R4 + 8 (zero beyond R): the unfolded table conv4 reads
+__global__ void bloom_wext_kernel(const float *wtab, float *wext, int R) {
+    const int R4 = (R + 3) & ~3, n = 2 * R4 + 8, stride = R + 1 + WPAD;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int d = i - (R4 + 3);
+    d = d < 0 ? -d : d;
+    for (int c = 0; c < 3; ++c) wext[c * n + i] = d <= R ? wtab[c * stride + d] : 0.0f;
+}
+
 // wsum[c][x] = sum over taps d = -R..R with 0 <= x + d < n of w_c[|d|], in tap order
-__global__ void bloom_wsum_kernel(const float *wtab, float *wsum, int R, int pad, int n) {
+__global__ void bloom_wsum_kernel(const float *wtab, float *wsum, int R, int n) {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n) return;
-    int stride = R + 1 + pad;
+    int stride = R + 1 + WPAD;
     float s0 = 0, s1 = 0, s2 = 0;
     for (int d = -R; d <= R; ++d) {
         int q = x + d;
@@ -53,107 +69,147 @@ __global__ void bloom_wsum_kernel(const float *wtab, float *wsum, int R, int pad
     wsum[2 * n + x] = s2;
 }
 
-// grid (ceil(W/HB), rows).  hblur row index = local row + R.
-__global__ __launch_bounds__(HB) void bloom_h_kernel(const float *__restrict__ disk, float *__restrict__ hblur,
-                                                     const float *__restrict__ wtab, const float *__restrict__ wsum_h,
-                                                     int W, int rows, int R, int pad) {
-    extern __shared__ float lds[];
-    const int span = HB + 2 * R;
-    float *px = lds;                 // 3 * span, planar
-    float *wt = lds + 3 * span;      // 3 * (R + 1)
-    const int x0 = blockIdx.x * HB;
-    const int row = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int wstride = R + 1 + pad;
-
-    const float *src = disk + (size_t)row * W * 3;
-    for (int k = tid; k < span * 3; k += HB) {
-        int p = k / 3, c = k - p * 3;
-        int x = x0 - R + p;
-        float v = (x >= 0 && x < W) ? src[(size_t)x * 3 + c] : 0.0f;
-        px[c * span + p] = v;
+// 4 adjacent outputs k = 0..3 at window index R4 + k from the 16-byte aligned window `win`
+// (win[4m + e], m < M): acc[k] += sum_{m,e} win[4m + e] * w[|4m + e - k - R4|].  `wx` is the channel's
+// symmetric weight table unfolded to wx[i] = w[|i - (R4 + 3)|] (zero beyond R), so the seven weights
+// of block m are the consecutive entries wx[4m .. 4m + 6]: uniform across the wave, fetched with
+// scalar loads from one base address, no per-weight address arithmetic.
+__device__ __forceinline__ void conv4(const float *__restrict__ win, int M, const float *__restrict__ wx, float acc[4]) {
+    for (int m = 0; m < M; ++m) {
+        const float4 v = *reinterpret_cast<const float4 *>(win + 4 * m);
+        const float *__restrict__ wp = wx + 4 * m;
+        float w[7];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) w[t] = wp[t];
+        acc[0] = fmaf(v.x, w[3], fmaf(v.y, w[4], fmaf(v.z, w[5], fmaf(v.w, w[6], acc[0]))));
+        acc[1] = fmaf(v.x, w[2], fmaf(v.y, w[3], fmaf(v.z, w[4], fmaf(v.w, w[5], acc[1]))));
+        acc[2] = fmaf(v.x, w[1], fmaf(v.y, w[2], fmaf(v.z, w[3], fmaf(v.w, w[4], acc[2]))));
+        acc[3] = fmaf(v.x, w[0], fmaf(v.y, w[1], fmaf(v.z, w[2], fmaf(v.w, w[3], acc[3]))));
     }
-    for (int k = tid; k < 3 * (R + 1); k += HB) {
-        int c = k / (R + 1), d = k - c * (R + 1);
-        wt[k] = wtab[c * wstride + d];
-    }
-    __syncthreads();
-
-    const int x = x0 + tid;
-    if (x >= W) return;
-    float s0 = 0, s1 = 0, s2 = 0;
-    const float *p0 = px + tid, *p1 = px + span + tid, *p2 = px + 2 * span + tid;
-    const float *w0 = wt, *w1 = wt + (R + 1), *w2 = wt + 2 * (R + 1);
-    for (int d = -R; d <= R; ++d) {
-        int ad = d < 0 ? -d : d;
-        s0 = fmaf(p0[R + d], w0[ad], s0);
-        s1 = fmaf(p1[R + d], w1[ad], s1);
-        s2 = fmaf(p2[R + d], w2[ad], s2);
-    }
-    const size_t plane = (size_t)(rows + 2 * R) * W;
-    const size_t o = (size_t)(row + R) * W + x;
-    hblur[o] = s0 / wsum_h[x];
-    hblur[plane + o] = s1 / wsum_h[W + x];
-    hblur[2 * plane + o] = s2 / wsum_h[2 * W + x];
 }
 
-// grid (ceil(W/256), ceil(rows/TY)).
-__global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ hblur, const float *__restrict__ bg,
-                                                      const float *__restrict__ disk, float *__restrict__ blur_out,
-                                                      float *__restrict__ final_out, const float *__restrict__ wtab,
-                                                      const float *__restrict__ wsum_v, int W, int H, int row0,
-                                                      int rows, int R, int pad, int with_bloom) {
-    extern __shared__ float wt[];  // 3 * (R + 1 + pad)
-    const int wstride = R + 1 + pad;
-    for (int k = threadIdx.x; k < 3 * wstride; k += blockDim.x) wt[k] = wtab[k];
+// grid (ceil(W / 1024), rows).  hblur row index = local row + R.
+__global__ __launch_bounds__(256) void bloom_h_kernel(const float *__restrict__ disk, float *__restrict__ hblur,
+                                                      const float *__restrict__ wext,
+                                                      const float *__restrict__ wsum_h, int W, int rows, int R) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int R4 = (R + 3) & ~3;
+    const int span = HB_PIX + 2 * R4 + 4;          // per-channel window, multiple of 4
+    const int x0 = blockIdx.x * HB_PIX;
+    const int row = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int xstride = 2 * R4 + 8;
+
+    // stage pixels [x0 - R4, x0 + 1024 + R4 + 4) of this row, de-interleaved to planar; zero outside
+    const float *src = disk + (size_t)row * W * 3;
+    for (int k = tid; k < span * 3; k += 256) {
+        int p = k / 3, c = k - p * 3;
+        int x = x0 - R4 + p;
+        lds[c * span + p] = (x >= 0 && x < W) ? src[(size_t)x * 3 + c] : 0.0f;
+    }
     __syncthreads();
 
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y0 = blockIdx.y * TY;  // local row of the first output
+    const int x = x0 + 4 * tid;
     if (x >= W) return;
-
-    float acc[TY][3];
+    const int M = (2 * R4) / 4 + 1;                // covers window indices 4 tid .. 4 tid + 2 R4 + 3
+    const size_t plane = (size_t)(rows + 2 * R) * W;
+    const size_t o = (size_t)(row + R) * W + x;
 #pragma unroll
-    for (int k = 0; k < TY; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
+    for (int c = 0; c < 3; ++c) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        conv4(lds + c * span + 4 * tid, M, wext + c * xstride, acc);
+        float *dst = hblur + c * plane + o;
+        const float *ws = wsum_h + c * W + x;
+        if (x + 3 < W && (W & 3) == 0) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(acc[0] / ws[0], acc[1] / ws[1], acc[2] / ws[2], acc[3] / ws[3]);
+        } else {
+            for (int k = 0; k < 4 && x + k < W; ++k) dst[k] = acc[k] / ws[k];
+        }
+    }
+}
+
+// grid (ceil(W / 32), ceil(rows / 128)).  Thread = (column, row-lane); 4 groups of 4 rows each.
+__global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ hblur, const float *__restrict__ bg,
+                                                      const float *__restrict__ disk, float *__restrict__ blur_out,
+                                                      float *__restrict__ final_out, const float *__restrict__ wext,
+                                                      const float *__restrict__ wsum_v, int W, int H, int row0,
+                                                      int rows, int R, int S, int with_bloom) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [VB_COLS][S], column-major tile
+    const int R4 = (R + 3) & ~3;
+    const int col = threadIdx.x & (VB_COLS - 1);
+    const int lane_g = threadIdx.x >> 5;           // 0..7
+    const int x = blockIdx.x * VB_COLS + col;
+    const int y0 = blockIdx.y * VB_ROWS;           // local row of the first output of the tile
+    const int xstride = 2 * R4 + 8;
+    const int tile_rows = VB_ROWS + 2 * R4 + 4;
+    const int M = (2 * R4) / 4 + 1;
+
+    float res[4][4][3];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) res[g][k][0] = res[g][k][1] = res[g][k][2] = 0.0f;
 
     if (with_bloom) {
         const size_t plane = (size_t)(rows + 2 * R) * W;
-        for (int t = 0; t < TY + 2 * R; ++t) {
-            const int yl = y0 - R + t;       // local row of this input
-            const int yg = yl + row0;        // image row
-            if (yg < 0 || yg >= H) continue; // out-of-image taps are skipped
-            const size_t o = (size_t)(yl + R) * W + x;
-            const float v0 = hblur[o], v1 = hblur[plane + o], v2 = hblur[2 * plane + o];
 #pragma unroll
-            for (int k = 0; k < TY; ++k) {
-                int dist = t - R - k;
-                dist = dist < 0 ? -dist : dist;  // <= R + TY - 1 < wstride; zero weight beyond R
-                acc[k][0] = fmaf(v0, wt[dist], acc[k][0]);
-                acc[k][1] = fmaf(v1, wt[wstride + dist], acc[k][1]);
-                acc[k][2] = fmaf(v2, wt[2 * wstride + dist], acc[k][2]);
+        for (int c = 0; c < 3; ++c) {
+            __syncthreads();
+            // stage rows [y0 - R4, y0 + 128 + R4 + 4) x 32 columns of plane c, transposed
+            for (int k = threadIdx.x; k < tile_rows * VB_COLS; k += 256) {
+                int r = k >> 5, cc = k & (VB_COLS - 1);
+                int yl = y0 - R4 + r;              // local row
+                int yg = yl + row0;                // image row
+                int xx = blockIdx.x * VB_COLS + cc;
+                float v = 0.0f;
+                // rows outside the image are skipped taps; rows outside this context's halo cannot be
+                // reached by a tap (|d| <= R) of one of its outputs
+                if (yg >= 0 && yg < H && yl >= -R && yl < rows + R && xx < W) v = hblur[c * plane + (size_t)(yl + R) * W + xx];
+                lds[cc * S + r] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int grp = lane_g + 8 * g;    // group of 4 rows inside the tile
+                float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                conv4(lds + col * S + 4 * grp, M, wext + c * xstride, acc);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) res[g][k][c] = acc[k];
             }
         }
     }
+    if (x >= W) return;
 #pragma unroll
-    for (int k = 0; k < TY; ++k) {
-        const int yl = y0 + k;
-        if (yl >= rows) break;
-        const int yg = yl + row0;
-        float b0 = 0, b1 = 0, b2 = 0;
-        if (with_bloom) {
-            b0 = acc[k][0] / wsum_v[yg];
-            b1 = acc[k][1] / wsum_v[H + yg];
-            b2 = acc[k][2] / wsum_v[2 * H + yg];
+    for (int g = 0; g < 4; ++g) {
+        const int grp = lane_g + 8 * g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yl = y0 + 4 * grp + k;
+            if (yl >= rows) continue;
+            const int yg = yl + row0;
+            float b0 = 0, b1 = 0, b2 = 0;
+            if (with_bloom) {
+                b0 = res[g][k][0] / wsum_v[yg];
+                b1 = res[g][k][1] / wsum_v[H + yg];
+                b2 = res[g][k][2] / wsum_v[2 * H + yg];
+            }
+            const size_t o = ((size_t)yl * W + x) * 3;
+            blur_out[o + 0] = b0;
+            blur_out[o + 1] = b1;
+            blur_out[o + 2] = b2;
+            // render.py:3912 / 3918: clip(img + disk [+ blur], 0, 1)
+            final_out[o + 0] = fminf(fmaxf(bg[o + 0] + disk[o + 0] + b0, 0.0f), 1.0f);
+            final_out[o + 1] = fminf(fmaxf(bg[o + 1] + disk[o + 1] + b1, 0.0f), 1.0f);
+            final_out[o + 2] = fminf(fmaxf(bg[o + 2] + disk[o + 2] + b2, 0.0f), 1.0f);
         }
-        const size_t o = ((size_t)yl * W + x) * 3;
-        blur_out[o + 0] = b0;
-        blur_out[o + 1] = b1;
-        blur_out[o + 2] = b2;
-        // render.py:3912 / 3918: clip(img + disk [+ blur], 0, 1)
-        final_out[o + 0] = fminf(fmaxf(bg[o + 0] + disk[o + 0] + b0, 0.0f), 1.0f);
-        final_out[o + 1] = fminf(fmaxf(bg[o + 1] + disk[o + 1] + b1, 0.0f), 1.0f);
-        final_out[o + 2] = fminf(fmaxf(bg[o + 2] + disk[o + 2] + b2, 0.0f), 1.0f);
     }
+}
+
+int v_stride(int R) {   // LDS column stride: >= tile rows, multiple of 4 with an odd quotient (bank spread)
+    const int R4 = (R + 3) & ~3;
+    int s = VB_ROWS + 2 * R4 + 4;
+    if (((s >> 2) & 1) == 0) s += 4;
+    return s;
 }
 
 }  // namespace
@@ -162,43 +218,46 @@ int32_t bhr_bloom_prepare(bhr_ctx *ctx) {
     if (ctx->bloom_ready) return BHR_OK;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     const int R = ctx->bloom_R;
-    const int pad = TY;
-    const int n = R + 1 + pad;
+    const int n = R + 1 + WPAD;
     // render.py:3915: sigma_scale = (width / 640.0) ** 2 in Python floats, passed as f32
     const float sigma_scale = (float)(((double)W / 640.0) * ((double)W / 640.0));
-    hipLaunchKernelGGL(bloom_weights_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_wtab, R, pad,
-                       sigma_scale);
-    hipLaunchKernelGGL(bloom_wsum_kernel, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wtab,
-                       ctx->d_wsum_h, R, pad, W);
-    hipLaunchKernelGGL(bloom_wsum_kernel, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wtab,
-                       ctx->d_wsum_v, R, pad, H);
+    hipLaunchKernelGGL(bloom_weights_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_wtab, R, sigma_scale);
+    {
+        const int R4 = (R + 3) & ~3, nx = 2 * R4 + 8;
+        hipLaunchKernelGGL(bloom_wext_kernel, dim3((nx + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_wtab, ctx->d_wext, R);
+    }
+    hipLaunchKernelGGL(bloom_wsum_kernel, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wtab, ctx->d_wsum_h, R, W);
+    hipLaunchKernelGGL(bloom_wsum_kernel, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wtab, ctx->d_wsum_v, R, H);
     BHR_HIP(hipGetLastError());
+    const size_t v_lds = (size_t)VB_COLS * v_stride(R) * sizeof(float);
+    if (v_lds > 48 * 1024)
+        BHR_HIP(hipFuncSetAttribute((const void *)bloom_v_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v_lds));
     ctx->bloom_ready = 1;
     return BHR_OK;
 }
 
 int32_t bhr_launch_bloom_h(bhr_ctx *ctx) {
-    const int W = ctx->cfg.width, R = ctx->bloom_R, pad = TY;
+    const int W = ctx->cfg.width, R = ctx->bloom_R;
     int32_t rc = bhr_bloom_prepare(ctx);
     if (rc) return rc;
-    dim3 grid((W + HB - 1) / HB, ctx->rows), block(HB);
-    size_t lds = (size_t)(3 * (HB + 2 * R) + 3 * (R + 1)) * sizeof(float);
-    hipLaunchKernelGGL(bloom_h_kernel, grid, block, lds, ctx->stream, ctx->d_disk, ctx->d_hblur, ctx->d_wtab,
-                       ctx->d_wsum_h, W, ctx->rows, R, pad);
+    const int R4 = (R + 3) & ~3;
+    dim3 grid((W + HB_PIX - 1) / HB_PIX, ctx->rows), block(256);
+    size_t lds = (size_t)3 * (HB_PIX + 2 * R4 + 4) * sizeof(float);
+    hipLaunchKernelGGL(bloom_h_kernel, grid, block, lds, ctx->stream, ctx->d_disk, ctx->d_hblur, ctx->d_wext,
+                       ctx->d_wsum_h, W, ctx->rows, R);
     BHR_HIP(hipGetLastError());
     return BHR_OK;
 }
 
 int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom) {
-    const int W = ctx->cfg.width, H = ctx->cfg.height, R = ctx->bloom_R, pad = TY;
-    if (with_bloom) {
-        int32_t rc = bhr_bloom_prepare(ctx);
-        if (rc) return rc;
-    }
-    dim3 grid((W + 255) / 256, (ctx->rows + TY - 1) / TY), block(256);
-    size_t lds = (size_t)3 * (R + 1 + pad) * sizeof(float);
+    const int W = ctx->cfg.width, H = ctx->cfg.height, R = ctx->bloom_R;
+    int32_t rc = bhr_bloom_prepare(ctx);
+    if (rc) return rc;
+    const int S = v_stride(R);
+    dim3 grid((W + VB_COLS - 1) / VB_COLS, (ctx->rows + VB_ROWS - 1) / VB_ROWS), block(256);
+    size_t lds = with_bloom ? (size_t)VB_COLS * S * sizeof(float) : 0;
     hipLaunchKernelGGL(bloom_v_kernel, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk,
-                       ctx->d_blur, ctx->d_final, ctx->d_wtab, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, pad,
+                       ctx->d_blur, ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S,
                        with_bloom);
     BHR_HIP(hipGetLastError());
     return BHR_OK;
