@@ -195,7 +195,7 @@ void bhr_destroy(bhr_ctx *ctx) {
     free_bg(ctx);
     void *bufs[] = {ctx->d_skybox, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_final_u8, ctx->d_hblur,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_queue, ctx->d_noise_in,
-                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext};
+                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

@@ -48,3 +48,21 @@ extern "C" int32_t bhr_disk_v2_eval(bhr_ctx *ctx, const bhr_disk_v2_params *p, i
     if (max_out) { max_out[0] = mx[0]; max_out[1] = mx[1]; }
     return BHR_OK;
 }
+
+extern "C" int32_t bhr_set_disk_source(bhr_ctx *ctx, int32_t source, const bhr_disk_v2_params *p, double norm_shear,
+                                       double norm_hotspot, double t_peak) {
+    if (!ctx || (source != BHR_DISK_TEXTURE && source != BHR_DISK_V2)) return bhr_fail(BHR_ERR_INVALID, "bhr_set_disk_source: bad argument");
+    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    if (source == BHR_DISK_V2) {
+        if (!p || !(norm_shear > 0.0) || !(norm_hotspot > 0.0) || !(t_peak > 0.0))
+            return bhr_fail(BHR_ERR_INVALID, "bhr_set_disk_source: Disk V2 needs parameters and positive normalisation constants");
+        if (!ctx->d_dv2_params) BHR_HIP(hipMalloc((void **)&ctx->d_dv2_params, sizeof(bhr_disk_v2_params)));
+        BHR_HIP(hipMemcpyAsync(ctx->d_dv2_params, p, sizeof(*p), hipMemcpyHostToDevice, ctx->stream));
+        BHR_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->dv2_norm[0] = norm_shear;
+        ctx->dv2_norm[1] = norm_hotspot;
+        ctx->dv2_norm[2] = t_peak;
+    }
+    ctx->disk_source = source;
+    return BHR_OK;
+}

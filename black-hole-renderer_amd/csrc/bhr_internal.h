@@ -53,6 +53,8 @@ struct BhrMarchArgs {
     float *disk;             // (rows, width, 3)
     unsigned long long *ray_steps;
     unsigned int *queue;     // persistent-wave work counter (zeroed before launch)
+    const bhr_disk_v2_params *dv2;   // non-null: analytic Disk V2 source instead of the texture
+    double dv2_norm_shear, dv2_norm_hotspot, dv2_t_peak;
     int32_t n_tiles;         // 8x8 pixel tiles in the row block
     int32_t tiles_x;
 };
@@ -93,6 +95,10 @@ struct bhr_ctx {
     float *d_stats_scratch;    // density | temp_struct | histogram | row results
     size_t stats_scratch_elems;
     int32_t stats_prepared;
+    // analytic disk source
+    int32_t disk_source;
+    bhr_disk_v2_params *d_dv2_params;
+    double dv2_norm[3];        // max|raw shear|, max|raw hotspot| on the reference grid, peak T_mid
 
     // frame buffers for rows [row0,row1)
     float *d_bg, *d_disk;      // (rows, W, 3)

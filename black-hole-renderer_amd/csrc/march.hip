@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "bhr_internal.h"
+#include "disk_v2_device.h"
 
 #ifndef BHR_MARCH_STRICT
 #define BHR_MARCH_STRICT 0
@@ -262,6 +263,35 @@ __device__ __forceinline__ V3 apply_g_factor(const BhrMarchArgs &a, V3 base_colo
     return out;
 }
 
+// Analytic disk source (bhr_set_disk_source, BHR_DISK_V2): emission colour and opacity straight from
+// the Disk V2 model in binary64 instead of a texture lookup -- temperature T_mid(r) F(r, phi) and
+// density rho_mid(r) F(r, phi) with F = F_mode F_shear F_hotspot (disk_v2/physical_fields.py,
+// structure_modulations.py), pattern advected with the model's own Omega(r).  The mapping to RGBA is
+// the compose kernel's (render.py:3192-3194, 3243-3257): t = clamp(T / T_peak), T_K = T_min + t (T_max -
+// T_min), rgb = blackbody(T_K) sqrt(t) with blue <= red, alpha = clamp(rho).  The reference never wired
+// disk_v2 into its renderer (docs/design_ad_v2.md Phase 4), so this mapping is this build's choice.
+__device__ __forceinline__ float4 disk_v2_rgba(const BhrMarchArgs &a, float hit_x, float hit_y) {
+    const bhr_disk_v2_params &p = *a.dv2;
+    double r = sqrt((double)hit_x * hit_x + (double)hit_y * hit_y);
+    double phi = atan2((double)hit_y, (double)hit_x) + (double)a.t_offset * dv2::omega_field(r, p);
+    double F = dv2::structure_total(r, phi, p, a.dv2_norm_shear, a.dv2_norm_hotspot);
+    double t = fmin(fmax(dv2::t_mid(r, p) * F / a.dv2_t_peak, 0.0), 1.0);
+    double rho = fmin(fmax(dv2::rho_mid(r, p) * F, 0.0), 1.0);
+    const float t_factor = (BHR_DISK_COLOR_TEMPERATURE - 4500.0f) / (6500.0f - 2700.0f);
+    const float T_min = 2000.0f + t_factor * 1000.0f, T_max = 9000.0f + t_factor * 3000.0f;
+    float tf = (float)t;
+    float tk = (T_min + tf * (T_max - T_min)) / 100.0f;
+    float cr = 1.0f, cg, cb = 1.0f;   // _color_temp_to_tint (render.py:2407-2437)
+    if (tk > 66.0f) cr = fminf(fmaxf(1.292936f * powf(fmaxf(tk - 60.0f, 0.0001f), -0.1332047592f), 0.0f), 1.0f);
+    if (tk <= 66.0f) cg = fminf(fmaxf(0.390082f * logf(fmaxf(tk, 0.0001f)) - 0.631841f, 0.0f), 1.0f);
+    else cg = fminf(fmaxf(1.129891f * powf(fmaxf(tk - 60.0f, 0.0001f), -0.0755148492f), 0.0f), 1.0f);
+    if (tk < 66.0f) cb = tk <= 19.0f ? 0.0f : fminf(fmaxf(0.543207f * logf(fmaxf(tk - 10.0f, 0.0001f)) - 1.19625f, 0.0f), 1.0f);
+    cb = fminf(cb, cr);
+    float lum = fminf(fmaxf(sqrtf(tf), 0.0f), 1.0f);
+    return make_float4(fminf(fmaxf(cr * lum, 0.0f), 1.0f), fminf(fmaxf(cg * lum, 0.0f), 1.0f), fminf(fmaxf(cb * lum, 0.0f), 1.0f),
+                       (float)rho);
+}
+
 // Shared by both builds: shade one disk crossing and composite it front to back
 // (render.py:2951-3002).  hit_x/hit_y: crossing point; to_cam: -direction at the START of the
 // step (render.py:2954); hdx/hdy: x,y components of the hit differentials (DIFF only).
@@ -282,7 +312,7 @@ struct Pending {
     float dxx, dxy, dyx, dyy;   // DIFF only
     int valid;
 };
-template <bool DIFF>
+template <bool DIFF, bool DV2>
 __device__ __forceinline__ void shade_hit(const BhrMarchArgs &a, Shade &sh, float hit_x, float hit_y, V3 to_cam,
                                           float hdx_x, float hdx_y, float hdy_x, float hdy_y) {
     float hit_r = sqrtf(hit_x * hit_x + hit_y * hit_y);
@@ -306,7 +336,10 @@ __device__ __forceinline__ void shade_hit(const BhrMarchArgs &a, Shade &sh, floa
         lod = fminf(fmaxf(lod, 0.0f), 3.0f);
         lod_i = (int)fminf(fmaxf(lod, 0.0f), (float)(BHR_NUM_MIP_LEVELS - 1));
     }
-    float4 rgba = sample_disk_level(a.sc, hit_x, hit_y, a.r_inner, a.r_outer, a.t_offset, lod_i);
+    // DV2 is a separate kernel instantiation: the binary64 model code (and its registers) never
+    // touches the texture kernels
+    float4 rgba = DV2 ? disk_v2_rgba(a, hit_x, hit_y)
+                      : sample_disk_level(a.sc, hit_x, hit_y, a.r_inner, a.r_outer, a.t_offset, lod_i);
     float base_alpha = fminf(rgba.w, 0.999f);
     float disk_alpha = 1.0f - powf(1.0f - base_alpha, BHR_DISK_ALPHA_GAIN);
     V3 col = apply_g_factor(a, mk(rgba.x, rgba.y, rgba.z), mk(hit_x, hit_y, hit_z), hit_r, to_cam);
@@ -360,7 +393,7 @@ __device__ __forceinline__ V3 pixel_ray(const BhrMarchArgs &a, int i, int j_loca
 // =============================================================================
 // strict build: render.py:2854-3006 operation by operation, 3-D state
 // =============================================================================
-template <bool DIFF>
+template <bool DIFF, bool DV2 = false>
 struct Ray {
     V3 p, d;
     float m15L2;   // -1.5 * L2
@@ -514,7 +547,7 @@ struct Ray {
     }
 
     __device__ __forceinline__ void shade_pending(const BhrMarchArgs &a) {
-        shade_hit<DIFF>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
+        shade_hit<DIFF, DV2>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
         pend.valid = 0;
     }
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, esc, sh); }
@@ -534,7 +567,7 @@ struct Ray {
 // pair coupled through the projection term of the Jacobian and an out-of-plane component that
 // sees only the isotropic term:  J d = c (d - 5 s (s.d)/r^2).
 // =============================================================================
-template <bool DIFF>
+template <bool DIFF, bool DV2 = false>
 struct Ray {
     float u, w, du, dw;   // position / direction along (g1, g2)
     float m15L2;          // -1.5 * L2
@@ -728,7 +761,7 @@ struct Ray {
     }
 
     __device__ __forceinline__ void shade_pending(const BhrMarchArgs &a) {
-        shade_hit<DIFF>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
+        shade_hit<DIFF, DV2>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
         pend.valid = 0;
     }
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, to3d(du, dw), sh); }
@@ -749,7 +782,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // ring) evenly.  An XCD-banded remap was measured and rejected (-13 %: the kernel is VALU
 // bound, texture traffic is negligible, and bands of rows differ in cost).
 // ---------------------------------------------------------------------------
-template <bool DIFF>
+template <bool DIFF, bool DV2 = false>
 __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     const int lane = threadIdx.x & 63;
     // one 8x8 tile per wave, tiles in row-major order; blockDim.x / 64 waves per block
@@ -759,7 +792,7 @@ __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     const int j = ty * 8 + (lane >> 3);
     const bool valid = tile < a.n_tiles && i < a.width && j < a.rows;
 
-    Ray<DIFF> ray;
+    Ray<DIFF, DV2> ray;
     ray.init(a, valid ? i : 0, valid ? j : 0);
     if (!valid) ray.done = 4;
     unsigned int executed = 0;
@@ -895,7 +928,7 @@ int32_t bhr_selftest_strict(bhr_ctx *ctx, unsigned long long *d_out4) {
 
 int32_t BHR_MARCH_RESOURCES(int32_t *vgprs, int32_t *lds, int32_t diff) {
     hipFuncAttributes at;
-    const void *f = diff ? (const void *)march_tile_kernel<true> : (const void *)march_tile_kernel<false>;
+    const void *f = diff ? (const void *)march_tile_kernel<true, false> : (const void *)march_tile_kernel<false, false>;
     BHR_HIP(hipFuncGetAttributes(&at, f));
     *vgprs = at.numRegs;
     *lds = (int32_t)at.sharedSizeBytes;
@@ -964,6 +997,10 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     const int slot = ctx->cur_slot;
     a.ray_steps = slot >= 0 ? ctx->d_steps_ring + slot : ctx->d_ray_steps;
     a.queue = ctx->d_queue;
+    a.dv2 = ctx->disk_source == BHR_DISK_V2 ? ctx->d_dv2_params : nullptr;
+    a.dv2_norm_shear = ctx->dv2_norm[0];
+    a.dv2_norm_hotspot = ctx->dv2_norm[1];
+    a.dv2_t_peak = ctx->dv2_norm[2];
     a.tiles_x = (c.width + 7) / 8;
     a.n_tiles = a.tiles_x * ((ctx->rows + 7) / 8);
 
@@ -975,7 +1012,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     if (flags & BHR_PERSISTENT) BHR_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned int), ctx->stream));
     BHR_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (slot >= 0) BHR_HIP(hipEventRecord(ctx->ring_ev[slot * 3 + 0], ctx->stream));
-    if (!(flags & BHR_PERSISTENT)) {
+    if (!(flags & BHR_PERSISTENT) || a.dv2) {   // the persistent schedule has no Disk V2 instantiation
         // waves per block: a block keeps its CU slot until its slowest wave has finished, so small
         // blocks shorten the tail; BHR_TILE_BLOCK overrides for experiments
         int bt = 256;
@@ -983,10 +1020,16 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         if (bt != 64 && bt != 128 && bt != 256) bt = 256;
         const int wpb = bt / 64;
         dim3 grid((a.n_tiles + wpb - 1) / wpb), block(bt);
-        if (want_diff)
-            hipLaunchKernelGGL(march_tile_kernel<true>, grid, block, 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(march_tile_kernel<false>, grid, block, 0, ctx->stream, a);
+        if (a.dv2) {   // analytic Disk V2 source: its own instantiations
+            if (want_diff)
+                hipLaunchKernelGGL((march_tile_kernel<true, true>), grid, block, 0, ctx->stream, a);
+            else
+                hipLaunchKernelGGL((march_tile_kernel<false, true>), grid, block, 0, ctx->stream, a);
+        } else if (want_diff) {
+            hipLaunchKernelGGL((march_tile_kernel<true, false>), grid, block, 0, ctx->stream, a);
+        } else {
+            hipLaunchKernelGGL((march_tile_kernel<false, false>), grid, block, 0, ctx->stream, a);
+        }
     } else {
         // enough resident waves to fill the chip; every wave drains the queue and exits
         int blocks = (a.n_tiles + 3) / 4;

@@ -274,6 +274,41 @@ def structure_modulation(r, phi, params: DiskV2Params, structure_params: DiskV2S
     return _restore(evaluate(F_TOTAL, cp, r, phi=phi), r, phi)
 
 
+# ---- analytic disk source for the renderer ----------------------------------------------------------
+def reference_norms(params: DiskV2Params, structure_params: DiskV2StructureParams | None = None, seed: int = 42,
+                    n_r: int = 512, n_phi: int = 2048, ctx=None):
+    """(cparams, max|raw shear|, max|raw hotspot|, peak T_mid) on the reference grid
+    r = linspace(r_in, r_out, n_r) x phi = linspace(0, 2 pi, n_phi, endpoint=False): the fixed constants
+    that replace the reference's "maximum over the evaluated array" when single rays are shaded."""
+    cp = pack_params(params, structure_params, shear_seed=seed, hotspot_seed=seed + 1)
+    r = np.linspace(params.r_in, params.r_out, n_r)
+    phi = np.linspace(0.0, 2.0 * np.pi, n_phi, endpoint=False)
+    rg, pg = np.meshgrid(r, phi, indexing="ij")
+    _, (m_sh, m_hs) = evaluate(F_TOTAL, cp, rg, phi=pg, ctx=ctx, return_max=True)
+    t_peak = float(np.max(evaluate(F_T_MID, cp, r, ctx=ctx)))
+    return cp, m_sh, m_hs, t_peak
+
+
+def disk_rgba(r, phi, cparams: _CParams, norm_shear: float, norm_hotspot: float, t_peak: float,
+              color_temp: float = 6000.0, ctx=None) -> np.ndarray:
+    """Host twin of csrc/march.hip: disk_v2_rgba (fields from the device, colour mapping in NumPy):
+    (..., 4) float32.  Used to bake textures and to test the in-kernel source."""
+    from .skybox import blackbody_rgb
+    F = evaluate(F_TOTAL, cparams, r, phi=phi, norm_shear=norm_shear, norm_hotspot=norm_hotspot, ctx=ctx)
+    T = evaluate(F_T_MID, cparams, np.broadcast_to(r, F.shape), ctx=ctx)
+    rho = evaluate(F_RHO_MID, cparams, np.broadcast_to(r, F.shape), ctx=ctx)
+    t = np.clip(T * F / t_peak, 0.0, 1.0).astype(np.float32)
+    t_factor = np.float32((color_temp - 4500.0) / (6500.0 - 2700.0))
+    T_min, T_max = np.float32(2000.0) + t_factor * np.float32(1000.0), np.float32(9000.0) + t_factor * np.float32(3000.0)
+    bb = blackbody_rgb((T_min + t * (T_max - T_min)).astype(np.float64))
+    bb[..., 2] = np.minimum(bb[..., 2], bb[..., 0])
+    lum = np.clip(np.sqrt(t), 0, 1)
+    out = np.empty(F.shape + (4,), dtype=np.float32)
+    out[..., :3] = np.clip(bb * lum[..., None], 0, 1)
+    out[..., 3] = np.clip(rho * F, 0.0, 1.0)
+    return out
+
+
 __all__ = ["DiskV2Params", "DiskV2StructureParams", "disk_half_thickness", "disk_radial_mask", "disk_radial_weight",
            "disk_vertical_weight", "disk_volume_mask", "density_field", "midplane_density_field",
            "midplane_temperature_field", "angular_velocity_field", "temperature_field", "weak_mode_modulation",

@@ -278,6 +278,22 @@ class HipRenderer:
                                             int(octaves), float(persistence), float(lacunarity), _lib.fptr(out)))
         return out
 
+    # ------------------------------------------------------------------ analytic disk source
+    def use_disk_v2(self, params=None, structure_params=None, seed: int = 42) -> None:
+        """Shade disk hits from the Disk V2 model inside the march kernel instead of the texture
+        (include/bhr_disk_v2.h: bhr_set_disk_source).  Pass ``params=None`` to go back to the texture."""
+        from . import disk_v2 as dv
+        lib = self._lib
+        lib.bhr_set_disk_source.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double]
+        lib.bhr_set_disk_source.restype = C.c_int32
+        if params is None:
+            _lib.check(lib.bhr_set_disk_source(self._ctx, 0, None, 0.0, 0.0, 0.0))
+            self._dv2 = None
+            return
+        cp, m_sh, m_hs, t_peak = dv.reference_norms(params, structure_params, seed, ctx=self._ctx)
+        _lib.check(lib.bhr_set_disk_source(self._ctx, 1, C.byref(cp), m_sh, m_hs, t_peak))
+        self._dv2 = (cp, m_sh, m_hs, t_peak)
+
     # ------------------------------------------------------------------ rendering
     def camera_uniforms(self, cam_pos, fov: float, frame: int = 0) -> _lib.Camera:
         """f64 camera -> the f32 uniforms of render.py:3880-3897."""

@@ -55,6 +55,15 @@ BHR_API int32_t bhr_disk_v2_eval(bhr_ctx *ctx, const bhr_disk_v2_params *params,
                                  const double *z, const double *phi, int64_t n, double norm_shear, double norm_hotspot,
                                  double *out, double *max_out);
 
+/* Disk source of the march kernel: BHR_DISK_TEXTURE (default) samples the disk texture / mip stack;
+ * BHR_DISK_V2 evaluates the Disk V2 model per hit in binary64 (temperature -> black-body colour,
+ * density -> opacity; csrc/march.hip: disk_v2_rgba).  norm_shear / norm_hotspot are the maxima of the raw
+ * structure sums on a reference grid (bhr_disk_v2_eval(..., max_out)), t_peak the maximum of T_mid(r). */
+#define BHR_DISK_TEXTURE 0
+#define BHR_DISK_V2 1
+BHR_API int32_t bhr_set_disk_source(bhr_ctx *ctx, int32_t source, const bhr_disk_v2_params *params, double norm_shear,
+                                    double norm_hotspot, double t_peak);
+
 #ifdef __cplusplus
 }
 #endif
