@@ -37,6 +37,8 @@ WORKLOADS = {
                disk_tilt=0.0),
     "4k": dict(width=3840, height=2160, cam_pos=[6.0, 0.0, 0.5], fov=90.0, step_size=0.1, anti_alias="lod_radius",
                disk_tilt=25.0),
+    "8k": dict(width=7680, height=4320, cam_pos=[6.0, 0.0, 0.5], fov=90.0, step_size=0.05, anti_alias="disabled",
+               disk_tilt=0.0),
 }
 
 
@@ -92,7 +94,13 @@ def main():
 
     import torch
     from bhr_amd import distributed as D
-    dist = D.init("nccl", local_rank) if world > 1 else None   # backend "nccl" is RCCL on ROCm
+    # backend "nccl" is RCCL on ROCm.  BHR_DIST_BACKEND=gloo + BHR_FORCE_DEVICE=0 rehearse the N > 1 code
+    # path with several ranks sharing one card (RCCL refuses duplicate GPUs).
+    backend = os.environ.get("BHR_DIST_BACKEND", "nccl")
+    if "BHR_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["BHR_FORCE_DEVICE"])
+    dist = D.init(backend, local_rank) if world > 1 else None
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from bhr_amd import workloads
     wl = WORKLOADS[args.workload]
@@ -134,7 +142,7 @@ def main():
     co = renderer.counters() if n_other else None
     # MAX over ranks of the time, SUM over ranks of the ray-steps each rank marched in the timed region
     elapsed, total_steps = D.aggregate_throughput(elapsed, float(c["ray_steps_sum"]) if c["frames_timed"] == args.steps
-                                                  else float(steps_per_frame) * args.steps, dist, device="cuda")
+                                                  else float(steps_per_frame) * args.steps, dist, device=red_dev)
 
     if rank == 0:
         n_frames = c["frames_timed"]

@@ -16,7 +16,8 @@ def find(sub, suffix):
 
 def short(name):
     for k in ("march_tile_kernel", "march_persistent_kernel", "bloom_h_kernel", "bloom_v_kernel", "background_kernel",
-              "compose_kernel", "mip_down_kernel", "quantize_u8_kernel", "bloom_w"):
+              "compose_kernel", "mip_down_kernel", "quantize_u8_kernel", "bloom_wext", "bloom_wsum", "bloom_weights",
+              "entity_kernel", "stats_fields_kernel", "select_hist_kernel", "row_stats_kernel", "disk_v2"):
         if k in name:
             tpl = "<diff>" if "ILb1E" in name or "<true>" in name else ""
             return k + tpl
