@@ -195,7 +195,8 @@ void bhr_destroy(bhr_ctx *ctx) {
     free_bg(ctx);
     void *bufs[] = {ctx->d_skybox, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_final_u8, ctx->d_hblur,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_queue, ctx->d_noise_in,
-                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params};
+                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params, ctx->d_glow_hw, ctx->d_glow_wh,
+                    ctx->d_flare_c0, ctx->d_flare_c12, ctx->d_flare_prog, ctx->d_flare_sums};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -392,6 +393,13 @@ int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctx));
     BHR_TRY(bhr_launch_bloom_v(ctx, with_bloom));
+    if (flags & BHR_LENS_FLARE) {
+        if (ctx->rows != ctx->cfg.height)
+            return bhr_fail(BHR_ERR_INVALID, "bhr_render: the lens flare needs whole-frame sums; use bhr_group_render for row blocks");
+        BHR_TRY(bhr_launch_flare_glow(ctx, true));
+        BHR_TRY(bhr_launch_flare_sums(ctx));
+        BHR_TRY(bhr_launch_flare_apply(ctx, nullptr));
+    }
     BHR_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     BHR_HIP(hipEventRecord(ctx->ring_ev[slot * 3 + 2], ctx->stream));
     ctx->ring_head += 1;
@@ -412,6 +420,40 @@ int32_t bhr_read_layer(bhr_ctx *ctx, int32_t layer, float *out) {
         default: return bhr_fail(BHR_ERR_INVALID, "bhr_read_layer: unknown layer %d", layer);
     }
     return download(ctx, out, src, (size_t)ctx->rows * ctx->cfg.width * 3 * sizeof(float));
+}
+
+int32_t bhr_write_layer(bhr_ctx *ctx, int32_t layer, const float *in) {
+    if (!ctx || !in) return bhr_fail(BHR_ERR_INVALID, "bhr_write_layer: bad argument");
+    BHR_TRY(use_device(ctx));
+    float *dst = nullptr;
+    switch (layer) {
+        case BHR_LAYER_FINAL: dst = ctx->d_final; break;
+        case BHR_LAYER_BG: dst = ctx->d_bg; break;
+        case BHR_LAYER_DISK: dst = ctx->d_disk; break;
+        case BHR_LAYER_BLUR: dst = ctx->d_blur; break;
+        default: return bhr_fail(BHR_ERR_INVALID, "bhr_write_layer: unknown layer %d", layer);
+    }
+    return upload(ctx, dst, in, (size_t)ctx->rows * ctx->cfg.width * 3 * sizeof(float));
+}
+
+int32_t bhr_lens_flare(bhr_ctx *ctx) {
+    if (!ctx) return bhr_fail(BHR_ERR_INVALID, "bhr_lens_flare: null ctx");
+    if (ctx->rows != ctx->cfg.height)
+        return bhr_fail(BHR_ERR_INVALID, "bhr_lens_flare: needs a whole-frame context (rows %d of %d)", ctx->rows, ctx->cfg.height);
+    BHR_TRY(use_device(ctx));
+    BHR_TRY(bhr_launch_flare_glow(ctx, true));
+    BHR_TRY(bhr_launch_flare_sums(ctx));
+    return bhr_launch_flare_apply(ctx, nullptr);
+}
+
+int32_t bhr_lens_flare_sums(bhr_ctx *ctx, double *out3) {
+    if (!ctx || !out3) return bhr_fail(BHR_ERR_INVALID, "bhr_lens_flare_sums: bad argument");
+    if (ctx->rows != ctx->cfg.height)
+        return bhr_fail(BHR_ERR_INVALID, "bhr_lens_flare_sums: needs a whole-frame context (rows %d of %d)", ctx->rows, ctx->cfg.height);
+    BHR_TRY(use_device(ctx));
+    BHR_TRY(bhr_launch_flare_glow(ctx, true));
+    BHR_TRY(bhr_launch_flare_sums(ctx));
+    return download(ctx, out3, ctx->d_flare_sums, 3 * sizeof(double));
 }
 
 int32_t bhr_read_final_u8(bhr_ctx *ctx, uint8_t *out) {
@@ -542,6 +584,30 @@ int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint3
         BHR_HIP(hipEventRecord(ctxs[k]->ev[2], ctxs[k]->stream));
         ctxs[k]->last_flags = (int32_t)flags;
         ctxs[k]->timing_valid = 1;
+    }
+    // phase 3b: lens flare -- tile 0 collects every tile's glow rows and sums the frame in NumPy's order
+    if (flags & BHR_LENS_FLARE) {
+        bhr_ctx *head = ctxs[0];
+        for (int k = 0; k < n; ++k) {
+            BHR_TRY(use_device(ctxs[k]));
+            BHR_TRY(bhr_launch_flare_glow(ctxs[k], k == 0));
+            BHR_HIP(hipEventRecord(ctxs[k]->ev[3], ctxs[k]->stream));
+        }
+        BHR_TRY(use_device(head));
+        for (int k = 1; k < n; ++k) {
+            BHR_HIP(hipStreamWaitEvent(head->stream, ctxs[k]->ev[3], 0));
+            BHR_HIP(hipMemcpyPeerAsync(head->d_glow_hw + (size_t)ctxs[k]->cfg.row0 * W, head->cfg.device, ctxs[k]->d_glow_hw,
+                                       ctxs[k]->cfg.device, (size_t)ctxs[k]->rows * W * sizeof(float), head->stream));
+        }
+        BHR_TRY(bhr_launch_flare_sums(head));
+        double tot[3];
+        BHR_HIP(hipMemcpyAsync(tot, head->d_flare_sums, sizeof(tot), hipMemcpyDeviceToHost, head->stream));
+        BHR_HIP(hipStreamSynchronize(head->stream));
+        for (int k = 0; k < n; ++k) {
+            BHR_TRY(use_device(ctxs[k]));
+            BHR_TRY(bhr_launch_flare_apply(ctxs[k], tot));
+            BHR_HIP(hipEventRecord(ctxs[k]->ev[2], ctxs[k]->stream));
+        }
     }
     // phase 4: gather the final tiles
     if (out_host) {

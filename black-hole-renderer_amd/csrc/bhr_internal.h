@@ -113,6 +113,14 @@ struct bhr_ctx {
     int32_t bloom_R, bloom_ready;
     unsigned long long *d_ray_steps;
     unsigned int *d_queue;
+    // lens flare (flare.hip)
+    float *d_glow_hw;          // glow rows (rows, W); (H, W) on the context that sums the frame
+    int64_t flare_glow_rows;
+    float *d_glow_wh;          // (W, H): the reference's memory order, summed the way NumPy sums it
+    float *d_flare_c0;         // per 8192-element chunk: sum glow (f32)
+    double *d_flare_c12;       // per chunk: sum x glow | sum y glow
+    int32_t *d_flare_prog;     // pairwise tree of the ragged last chunk
+    double *d_flare_sums;      // S0, S1, S2
     float *h_pinned;           // staging for readbacks
     size_t h_pinned_bytes;
 
@@ -139,6 +147,9 @@ int32_t bhr_selftest_strict(bhr_ctx *ctx, unsigned long long *d_out4);
 int32_t bhr_bloom_prepare(bhr_ctx *ctx);
 int32_t bhr_launch_bloom_h(bhr_ctx *ctx);
 int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom);
+int32_t bhr_launch_flare_glow(bhr_ctx *ctx, bool whole_frame);       // flare.hip
+int32_t bhr_launch_flare_sums(bhr_ctx *ctx);
+int32_t bhr_launch_flare_apply(bhr_ctx *ctx, const double *sums);    // sums == nullptr: device-resident totals
 int32_t bhr_launch_build_mips(bhr_ctx *ctx);
 int32_t bhr_launch_background(bhr_ctx *ctx, float t);
 int32_t bhr_launch_compose(bhr_ctx *ctx, float t_offset, int32_t enable_rt, float color_temp);

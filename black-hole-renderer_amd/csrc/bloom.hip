@@ -18,7 +18,7 @@
 //     vertical window is contiguous, epilogue fuses clip(bg + disk + blur) of render.py:3918.
 // The intermediate carries R halo rows on either side so that row-block tiles on different GPUs can
 // exchange them (bhr_group_render).  Summation order differs from the reference's tap order
-// (-R .. R) only by f32 rounding (tests: 2e-6 against the oracle's bloom).
+// (-R .. R) only by f32 rounding (tests: 2e-6 against the CPU restatement in the tests).
 #include "bhr_internal.h"
 
 namespace {

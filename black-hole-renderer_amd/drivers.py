@@ -193,12 +193,8 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
             continue
         cam_pos = orbit_position(static_cam_pos, frame, n_frames, orbit_degrees) if orbit else static_cam_pos
         t0 = time.time()
-        if renderer.lens_flare:
-            img = renderer.render(cam_pos, fov, frame=0)
-            img_u8 = (np.clip(img, 0, 1) * 255).astype(np.uint8)
-        else:
-            renderer.render_async(cam_pos, fov, frame=0)
-            img_u8 = renderer.read_final_u8()      # quantised on the device
+        renderer.render_async(cam_pos, fov, frame=0)   # lens flare, when enabled, is applied on the device
+        img_u8 = renderer.read_final_u8()              # quantised on the device
         elapsed = time.time() - t0
         rendered += 1
         if len(pending) >= 4:

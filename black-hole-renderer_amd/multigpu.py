@@ -33,7 +33,7 @@ def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
 
 
 def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_differentials=False,
-                 skip_bloom=False) -> np.ndarray:
+                 skip_bloom=False, lens_flare=False) -> np.ndarray:
     """Render one frame with the row-block renderers ``tiles`` (HipRenderer objects whose rows tile
     the image in order).  Returns the gathered (H, W, 3) float32 frame."""
     first = tiles[0]
@@ -42,6 +42,8 @@ def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_diff
     out = np.empty((first.height, first.width, 3), dtype=np.float32)
     cam = first.camera_uniforms(cam_pos, fov, frame)
     flags = first._flags(skip_differentials, skip_bloom)
+    if lens_flare:
+        flags |= _lib.LENS_FLARE
     _lib.check(lib.bhr_group_render(arr, len(tiles), C.byref(cam), flags, _lib.fptr(out)))
     return out
 
@@ -50,7 +52,6 @@ def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devi
     """render_image over ``gpus`` row blocks.  ``devices`` maps block k to a HIP device ordinal
     (default k); every device builds the same deterministic scene."""
     from .drivers import make_renderer, init_lifecycle_system, advance_lifecycle_frame
-    from .flare import apply_lens_flare
     devices = list(range(gpus)) if devices is None else list(devices)
     tiles = []
     for k, rows in enumerate(row_blocks(height, gpus)):
@@ -60,10 +61,7 @@ def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devi
             factories = init_lifecycle_system(r, n_r, n_phi, seed=42)
             advance_lifecycle_frame(r, factories, t=0.0, dt=0.0, recompute_stats=True)
         tiles.append(r)
-    img = group_render(tiles, cam_pos, fov)
-    if lens_flare:
-        disk = np.concatenate([t.read_layer(_lib.LAYER_DISK) for t in tiles], axis=0)
-        img = apply_lens_flare(img, disk)
+    img = group_render(tiles, cam_pos, fov, lens_flare=lens_flare)
     for t in tiles:
         t.close()
     return img

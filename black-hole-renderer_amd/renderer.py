@@ -14,7 +14,6 @@ import numpy as np
 
 from . import _lib
 from .camera import build_camera
-from .flare import apply_lens_flare
 from .textures import compute_edge_alpha, keplerian_omega_rows
 
 R_DISK_INNER_DEFAULT = 2.0   # render.py:433
@@ -316,12 +315,14 @@ class HipRenderer:
                 | {None: 0, "fast": _lib.FORCE_FAST, "strict": _lib.FORCE_STRICT}[math])
 
     def render_async(self, cam_pos, fov: float, frame: int = 0, skip_differentials: bool = False,
-                     skip_bloom: bool = False, compaction: bool = False, math=None) -> None:
+                     skip_bloom: bool = False, compaction: bool = False, math=None, lens_flare=None) -> None:
         """Launch march + bloom + combine; the frame stays in HBM (counterpart of render_to_field,
         render.py:3819-3863, without the GUI flip)."""
         cam = self.camera_uniforms(cam_pos, fov, frame)
-        _lib.check(self._lib.bhr_render(self._ctx, C.byref(cam), self._flags(skip_differentials, skip_bloom,
-                                                                            compaction, math)))
+        flags = self._flags(skip_differentials, skip_bloom, compaction, math)
+        if self.lens_flare if lens_flare is None else lens_flare:
+            flags |= _lib.LENS_FLARE          # device twin of _apply_lens_flare (render.py:3920-4028)
+        _lib.check(self._lib.bhr_render(self._ctx, C.byref(cam), flags))
 
     def sync(self) -> None:
         _lib.check(self._lib.bhr_sync(self._ctx))
@@ -331,6 +332,22 @@ class HipRenderer:
         _lib.check(self._lib.bhr_read_layer(self._ctx, layer, _lib.fptr(out)))
         return out
 
+    def write_layer(self, layer: int, data: np.ndarray) -> None:
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        if data.shape != (self.rows, self.width, 3):
+            raise ValueError(f"layer must be {(self.rows, self.width, 3)}, got {data.shape}")
+        _lib.check(self._lib.bhr_write_layer(self._ctx, layer, _lib.fptr(data)))
+
+    def apply_lens_flare(self) -> None:
+        """FINAL <- clip(FINAL + flare(DISK), 0, 1) on the device (_apply_lens_flare, render.py:3925-4028)."""
+        _lib.check(self._lib.bhr_lens_flare(self._ctx))
+
+    def lens_flare_sums(self) -> np.ndarray:
+        """(sum glow, sum x glow, sum y glow) of the disk layer, in NumPy's summation order."""
+        out = (C.c_double * 3)()
+        _lib.check(self._lib.bhr_lens_flare_sums(self._ctx, out))
+        return np.array(out[:], dtype=np.float64)
+
     def read_final_u8(self) -> np.ndarray:
         out = np.empty((self.rows, self.width, 3), dtype=np.uint8)
         _lib.check(self._lib.bhr_read_final_u8(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8))))
@@ -339,14 +356,11 @@ class HipRenderer:
     def render(self, cam_pos: List[float], fov: float, frame: int = 0,
                skip_differentials: bool = False, skip_bloom: bool = False) -> np.ndarray:
         """One frame -> (rows, width, 3) float32 in [0, 1]  (render.py:3865-3923)."""
+        if self.lens_flare and self.rows != self.height:
+            raise ValueError("lens flare needs whole-frame sums; render row blocks through "
+                             "bhr_amd.multigpu.group_render(..., lens_flare=True)")
         self.render_async(cam_pos, fov, frame, skip_differentials, skip_bloom)
-        final = self.read_layer(_lib.LAYER_FINAL)
-        if self.lens_flare:
-            if self.rows != self.height:
-                raise ValueError("lens flare needs the whole frame; render row blocks without it and "
-                                 "apply bhr_amd.flare.apply_lens_flare after the gather")
-            final = apply_lens_flare(final, self.read_layer(_lib.LAYER_DISK))
-        return final
+        return self.read_layer(_lib.LAYER_FINAL)
 
     def selftest(self) -> dict:
         """Device check of the strict march's exact sqrt / divide sequences (bhr_selftest)."""

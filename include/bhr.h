@@ -90,6 +90,7 @@ typedef struct {
 #define BHR_PERSISTENT         4u  /* persistent waves + queue refill instead of the tile schedule */
 #define BHR_FORCE_FAST         8u  /* this call only: fast arithmetic regardless of bhr_config.math_mode */
 #define BHR_FORCE_STRICT      16u  /* this call only: strict arithmetic regardless of bhr_config.math_mode */
+#define BHR_LENS_FLARE        32u  /* add the lens flare to the final layer on the device (render.py:3920-4028) */
 
 /* selectors for bhr_read_layer */
 typedef enum {
@@ -177,6 +178,17 @@ BHR_API int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);
 /* image_field/disk_layer_field/blur_field .to_numpy() and the final image,
  * for the context's rows: (row1-row0, width, 3) f32.  Synchronises. */
 BHR_API int32_t bhr_read_layer(bhr_ctx *ctx, int32_t layer, float *out);
+/* field.from_numpy() for a frame layer: replaces the context's rows of FINAL, BG, DISK or BLUR with
+ * caller data, e.g. to post-process a frame composed elsewhere.  Synchronises. */
+BHR_API int32_t bhr_write_layer(bhr_ctx *ctx, int32_t layer, const float *in);
+/* TaichiRenderer._apply_lens_flare(final, disk) (render.py:3925-4028) on the device, standalone:
+ * FINAL <- clip(FINAL + flare(DISK), 0, 1) for a whole-frame context.  bhr_render / bhr_group_render
+ * with BHR_LENS_FLARE run the same kernels after the combine.  Asynchronous. */
+BHR_API int32_t bhr_lens_flare(bhr_ctx *ctx);
+/* The three frame sums the flare is built from, as the reference computes them (render.py:3931-3939):
+ * out3 = { np.sum(glow) (f32 value), np.sum(x * glow), np.sum(y * glow) } with glow = max(DISK, axis=2),
+ * accumulated in NumPy's own summation order, hence bit-identical to it.  Synchronises. */
+BHR_API int32_t bhr_lens_flare_sums(bhr_ctx *ctx, double *out3);
 /* save_image()'s quantisation (clip*255 truncated to u8, render.py:423) done
  * on the device: (row1-row0, width, 3) u8.  Synchronises. */
 BHR_API int32_t bhr_read_final_u8(bhr_ctx *ctx, uint8_t *out);

