@@ -23,12 +23,6 @@ int32_t dev_alloc(T **p, size_t count) {
     return BHR_OK;
 }
 
-#define BHR_TRY(expr)            \
-    do {                         \
-        int32_t rc__ = (expr);   \
-        if (rc__ != BHR_OK) return rc__; \
-    } while (0)
-
 int32_t use_device(bhr_ctx *ctx) {
     BHR_HIP(hipSetDevice(ctx->cfg.device));
     return BHR_OK;
@@ -66,6 +60,18 @@ __global__ void quantize_u8_kernel(const float *__restrict__ src, uint8_t *__res
     // save_image: (np.clip(x, 0, 1) * 255).astype(np.uint8) -- truncation (render.py:423)
     for (; i < n; i += stride) dst[i] = (uint8_t)(int)(fminf(fmaxf(src[i], 0.0f), 1.0f) * 255.0f);
 }
+
+}  // namespace
+
+// FINAL (f32) -> d_final_u8 on the context's stream
+int32_t bhr_launch_quantize(bhr_ctx *ctx) {
+    const long long n = (long long)ctx->rows * ctx->cfg.width * 3;
+    hipLaunchKernelGGL(quantize_u8_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->d_final, ctx->d_final_u8, n);
+    BHR_HIP(hipGetLastError());
+    return BHR_OK;
+}
+
+namespace {
 
 void free_scene(bhr_ctx *ctx) {
     if (ctx->d_mips) (void)hipFree(ctx->d_mips);
@@ -459,10 +465,8 @@ int32_t bhr_lens_flare_sums(bhr_ctx *ctx, double *out3) {
 int32_t bhr_read_final_u8(bhr_ctx *ctx, uint8_t *out) {
     if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_read_final_u8: bad argument");
     BHR_TRY(use_device(ctx));
-    const long long n = (long long)ctx->rows * ctx->cfg.width * 3;
-    hipLaunchKernelGGL(quantize_u8_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->d_final, ctx->d_final_u8, n);
-    BHR_HIP(hipGetLastError());
-    return download(ctx, out, ctx->d_final_u8, (size_t)n);
+    BHR_TRY(bhr_launch_quantize(ctx));
+    return download(ctx, out, ctx->d_final_u8, (size_t)ctx->rows * ctx->cfg.width * 3);
 }
 
 int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {

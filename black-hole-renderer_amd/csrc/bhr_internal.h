@@ -139,6 +139,12 @@ int32_t bhr_fail(int32_t code, const char *fmt, ...);
                             __FILE__, __LINE__);                                            \
     } while (0)
 
+#define BHR_TRY(expr)                    \
+    do {                                 \
+        int32_t rc__ = (expr);           \
+        if (rc__ != BHR_OK) return rc__; \
+    } while (0)
+
 // launchers (each lives next to its kernels)
 int32_t bhr_launch_march(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);         // dispatches on math_mode
 int32_t bhr_launch_march_strict(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);  // march_strict.o
@@ -150,6 +156,7 @@ int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom);
 int32_t bhr_launch_flare_glow(bhr_ctx *ctx, bool whole_frame);       // flare.hip
 int32_t bhr_launch_flare_sums(bhr_ctx *ctx);
 int32_t bhr_launch_flare_apply(bhr_ctx *ctx, const double *sums);    // sums == nullptr: device-resident totals
+int32_t bhr_launch_quantize(bhr_ctx *ctx);                           // api.hip: FINAL -> u8 on the stream
 int32_t bhr_launch_build_mips(bhr_ctx *ctx);
 int32_t bhr_launch_background(bhr_ctx *ctx, float t);
 int32_t bhr_launch_compose(bhr_ctx *ctx, float t_offset, int32_t enable_rt, float color_temp);

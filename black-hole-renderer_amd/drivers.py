@@ -15,23 +15,27 @@ import json
 import os
 import shutil
 import time
-from concurrent.futures import ThreadPoolExecutor
 from typing import List, Optional
 
 import numpy as np
 
 from .camera import orbit_position
 from .lifecycle import make_factories
+from .output import FrameSink, VIDEO_LEVEL, png_write, quantize
 from .renderer import HipRenderer, R_DISK_INNER_DEFAULT, R_DISK_OUTER_DEFAULT
 from .skybox import load_or_generate_skybox
 from .textures import compute_disk_texture_resolution, load_disk_texture
 
 
 def save_image(image: np.ndarray, path: str) -> None:
-    """float image -> 8-bit PNG with truncation, not rounding (render.py:420-425)."""
-    from PIL import Image
+    """float image -> 8-bit PNG with truncation, not rounding (render.py:420-425).  Encoded by the
+    library (row bands deflated in parallel); non-PNG extensions go through PIL as in the reference."""
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-    Image.fromarray((np.clip(image, 0, 1) * 255).astype(np.uint8), "RGB").save(path)
+    if path.lower().endswith(".png"):
+        png_write(path, quantize(image))
+    else:
+        from PIL import Image
+        Image.fromarray(quantize(image), "RGB").save(path)
     print(f"Saved: {path}")
 
 
@@ -146,11 +150,12 @@ def assemble_video(temp_dir: str, n_frames: int, fps: int, output_path: str) -> 
 def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, fps: int, output_path: str,
                  fov: float, static_cam_pos: List[float], orbit: bool = False, resume: bool = False,
                  disk_rotation_speed: float = 0.1, orbit_degrees: float = 360.0, rank: int = 0, world: int = 1,
-                 assemble: bool = True, **_deprecated_kwargs) -> None:
+                 assemble: bool = True, png_level: int = VIDEO_LEVEL, sink_slots: int = 8, sink_workers: int = 0,
+                 **_deprecated_kwargs) -> None:
     """N frames -> PNGs (+ MP4) (render.py:4356-4511).  Frame f is rendered by rank f % world."""
-    from PIL import Image
     os.makedirs(os.path.dirname(output_path) or ".", exist_ok=True)
     temp_dir = _frames_dir(output_path)
+    submitted: List[int] = []
     progress_file = os.path.join(temp_dir, f"progress.json" if world == 1 else f"progress.rank{rank}.json")
     params = {"n_frames": n_frames, "fov": fov, "orbit": orbit, "disk_rotation_speed": disk_rotation_speed,
               "orbit_degrees": orbit_degrees}
@@ -165,18 +170,17 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
                 shutil.rmtree(temp_dir)
             os.makedirs(temp_dir, exist_ok=True)
         else:
-            completed = set(saved.get("completed", []))
+            completed = {f for f in saved.get("completed", [])
+                         if os.path.isfile(os.path.join(temp_dir, f"frame_{f:04d}.png"))}
             print(f"Resuming: {len(completed)}/{n_frames} frames already rendered")
     else:
         os.makedirs(temp_dir, exist_ok=True)
 
     total_t0 = time.time()
     rendered = 0
-    pool = ThreadPoolExecutor(max_workers=2)
-    pending = []
-
-    def _save_png(path, img_u8):
-        Image.fromarray(img_u8, "RGB").save(path)
+    # the reference saves through a 2-thread PIL pool (render.py:4412-4413); here the frame is quantised
+    # on the device, copied into a pinned ring and encoded by worker threads while the next frames render
+    sink = FrameSink(renderer, slots=sink_slots, workers=sink_workers, level=png_level)
 
     n_r, n_phi = renderer.dtex_h, renderer.dtex_w
     factories = init_lifecycle_system(renderer, n_r, n_phi, seed=42)
@@ -194,27 +198,28 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
         cam_pos = orbit_position(static_cam_pos, frame, n_frames, orbit_degrees) if orbit else static_cam_pos
         t0 = time.time()
         renderer.render_async(cam_pos, fov, frame=0)   # lens flare, when enabled, is applied on the device
-        img_u8 = renderer.read_final_u8()              # quantised on the device
+        sink.submit(os.path.join(temp_dir, f"frame_{frame:04d}.png"))
         elapsed = time.time() - t0
         rendered += 1
-        if len(pending) >= 4:
-            pending.pop(0).result()
-        pending.append(pool.submit(_save_png, os.path.join(temp_dir, f"frame_{frame:04d}.png"), img_u8))
-        completed.add(frame)
-        if rendered % 10 == 0 or frame >= n_frames - world:
+        submitted.append(frame)
+        if rendered % 50 == 0 or frame >= n_frames - world:
+            sink.drain()                                # progress.json only lists frames that are on disk
+            completed.update(submitted)
+            submitted.clear()
             with open(progress_file, "w") as f:
                 json.dump({"params": params, "completed": sorted(completed)}, f)
         if rendered % 100 == 0 or frame == n_frames - 1:
             print(f"  frame {frame}/{n_frames} {elapsed * 1e3:.1f} ms, done {len(completed)}")
 
-    for f in pending:
-        f.result()
-    pool.shutdown(wait=False)
+    frames_written, bytes_written = sink.drain()
+    sink.close()
+    completed.update(submitted)
     with open(progress_file, "w") as f:
         json.dump({"params": params, "completed": sorted(completed)}, f)
     if rendered:
         print(f"Session rendered {rendered} frames in {time.time() - total_t0:.1f} s "
-              f"({rendered / (time.time() - total_t0):.1f} fps incl. PNG encode)")
+              f"({rendered / (time.time() - total_t0):.1f} fps incl. PNG encode, "
+              f"{bytes_written / max(frames_written, 1) / 1e6:.2f} MB/frame, {sink.workers} encoder threads)")
     if world > 1 or not assemble:
         return       # rank 0 assembles after a barrier (cli.py)
     if len(completed) < n_frames:

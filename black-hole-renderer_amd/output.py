@@ -1,0 +1,95 @@
+"""Frame output: PNG files and the pipelined frame sink (include/bhr_output.h).
+
+Counterpart of save_image (render.py:420-425) and of the PIL thread pool in render_video
+(render.py:4412-4413, 4458-4467).  Decoded pixels are the reference's
+``(np.clip(frame, 0, 1) * 255).astype(np.uint8)``; the compressed bytes are this encoder's own.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+DEFAULT_LEVEL = 6          # PIL's default zlib level for PNG
+VIDEO_LEVEL = 1            # frames that are re-encoded into an MP4 anyway
+
+
+def _u8(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError(f"expected an (H, W, 3) uint8 image, got {a.dtype} {a.shape}")
+    return a
+
+
+def png_encode(rgb_u8: np.ndarray, level: int = DEFAULT_LEVEL, threads: int = 1) -> bytes:
+    """(H, W, 3) uint8 -> PNG file bytes."""
+    a = _u8(rgb_u8)
+    h, w = a.shape[:2]
+    lib = _lib.load()
+    cap = lib.bhr_png_bound(w, h)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_int64(0)
+    p8 = C.POINTER(C.c_uint8)
+    _lib.check(lib.bhr_png_encode(a.ctypes.data_as(p8), w, h, level, threads, out.ctypes.data_as(p8), cap, C.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def png_write(path: str, rgb_u8: np.ndarray, level: int = DEFAULT_LEVEL, threads: int = 0) -> None:
+    """Image.fromarray(rgb_u8).save(path) with row bands deflated on ``threads`` threads
+    (0: one per 256 rows, at most the CPUs of this process)."""
+    a = _u8(rgb_u8)
+    h, w = a.shape[:2]
+    if threads <= 0:
+        threads = max(1, min(len(os.sched_getaffinity(0)), h // 256))
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    _lib.check(_lib.load().bhr_png_write(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, level, threads))
+
+
+def quantize(image: np.ndarray) -> np.ndarray:
+    """save_image's 8-bit conversion: truncation, not rounding (render.py:423)."""
+    return (np.clip(image, 0, 1) * 255).astype(np.uint8)
+
+
+class FrameSink:
+    """Device frame -> PNG file without stalling the render stream.
+
+    ``submit(path)`` quantises the renderer's FINAL layer on the device, starts the copy into a pinned
+    host slot and returns; worker threads encode and write.  ``drain()`` waits for the files."""
+
+    def __init__(self, renderer, slots: int = 8, workers: int = 0, level: int = VIDEO_LEVEL):
+        if workers <= 0:
+            workers = max(1, min(16, len(os.sched_getaffinity(0)) - 1))
+        self._lib = _lib.load()
+        self._sink = C.c_void_p()
+        self._renderer = renderer          # keeps the context alive
+        _lib.check(self._lib.bhr_sink_create(renderer._ctx, slots, workers, level, C.byref(self._sink)))
+        self.workers, self.slots, self.level = workers, slots, level
+
+    def submit(self, path: str) -> None:
+        _lib.check(self._lib.bhr_sink_submit(self._sink, os.fsencode(path)))
+
+    def drain(self):
+        """-> (frames written, bytes written) since creation."""
+        frames, nbytes = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.bhr_sink_drain(self._sink, C.byref(frames), C.byref(nbytes)))
+        return frames.value, nbytes.value
+
+    def close(self) -> None:
+        if self._sink:
+            self._lib.bhr_sink_destroy(self._sink)
+            self._sink = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,41 @@
+/* bhr_output.h -- frame output of libbhr_hip.so: PNG encoding and the pipelined frame sink.
+ *
+ * Replaces the reference's host output path: save_image (render.py:420-425, PIL) for still images and
+ * the two-thread PIL pool of render_video (render.py:4412-4413, 4458-4467), which caps the video driver
+ * at a few frames per second once a frame renders in a millisecond.  Files are ordinary 8-bit RGB PNGs;
+ * the decoded pixels equal (np.clip(frame, 0, 1) * 255).astype(np.uint8) of the reference exactly,
+ * the compressed bytes differ (they also differ between PIL versions).
+ */
+#ifndef BHR_OUTPUT_H
+#define BHR_OUTPUT_H
+
+#include "bhr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Encode an (h, w, 3) u8 image.  level: zlib level 0..9 (PIL's default is 6).  threads > 1 deflates
+ * row bands in parallel and splices them into one stream.  out must hold bhr_png_bound(w, h) bytes. */
+BHR_API int64_t bhr_png_bound(int32_t w, int32_t h);
+BHR_API int32_t bhr_png_encode(const uint8_t *rgb, int32_t w, int32_t h, int32_t level, int32_t threads,
+                               uint8_t *out, int64_t cap, int64_t *out_len);
+/* Image.fromarray(rgb).save(path): encode and write atomically (path.tmp, then rename). */
+BHR_API int32_t bhr_png_write(const char *path, const uint8_t *rgb, int32_t w, int32_t h, int32_t level, int32_t threads);
+
+/* Frame sink.  bhr_sink_submit quantises the context's FINAL layer on the device (save_image's
+ * truncation), starts an asynchronous copy into one of `slots` pinned host buffers and returns; `workers`
+ * host threads wait for the copy, encode and write `path`.  The caller goes on to render the next frame
+ * on the same stream meanwhile.  submit blocks only while every slot is busy. */
+typedef struct bhr_sink bhr_sink;
+BHR_API int32_t bhr_sink_create(bhr_ctx *ctx, int32_t slots, int32_t workers, int32_t level, bhr_sink **out);
+BHR_API int32_t bhr_sink_submit(bhr_sink *sink, const char *path);
+/* Wait until every submitted frame is on disk; returns the first error a worker met, if any.
+ * frames_written / bytes_written may be NULL. */
+BHR_API int32_t bhr_sink_drain(bhr_sink *sink, int64_t *frames_written, int64_t *bytes_written);
+BHR_API void bhr_sink_destroy(bhr_sink *sink);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHR_OUTPUT_H */
