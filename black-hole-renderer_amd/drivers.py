@@ -150,7 +150,7 @@ def assemble_video(temp_dir: str, n_frames: int, fps: int, output_path: str) -> 
 def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, fps: int, output_path: str,
                  fov: float, static_cam_pos: List[float], orbit: bool = False, resume: bool = False,
                  disk_rotation_speed: float = 0.1, orbit_degrees: float = 360.0, rank: int = 0, world: int = 1,
-                 assemble: bool = True, png_level: int = VIDEO_LEVEL, sink_slots: int = 8, sink_workers: int = 0,
+                 assemble: bool = True, png_level: int = VIDEO_LEVEL, sink_slots: int = 0, sink_workers: int = 0,
                  **_deprecated_kwargs) -> None:
     """N frames -> PNGs (+ MP4) (render.py:4356-4511).  Frame f is rendered by rank f % world."""
     os.makedirs(os.path.dirname(output_path) or ".", exist_ok=True)

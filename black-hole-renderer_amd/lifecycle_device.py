@@ -41,15 +41,33 @@ def _bind(lib):
 
 
 # --------------------------------------------------------------------------- pair tables
+def _filament_static(e, n_r: int, omega_rows: np.ndarray, r_norm_all: np.ndarray):
+    """What does not change over a filament's life: its rows, the f64 radial weights (math.exp, as the
+    scalar code of the reference) and the rows' angular velocities."""
+    c = getattr(e, "_pair_static", None)
+    if c is None or c[0] != n_r:
+        rows = e.row_indices[(e.row_indices >= 0) & (e.row_indices < n_r)].astype(np.int64)
+        sigma_r = max(e.blob_sigma_r, 1e-6)
+        inv_2s_r = 0.5 / (sigma_r * sigma_r)
+        r_w = np.array([math.exp(-(r_norm_all[ri] - e.blob_base_r) ** 2 * inv_2s_r) for ri in rows], dtype=np.float64)
+        c = (n_r, rows, r_w, omega_rows[rows])
+        e._pair_static = c
+    return c
+
+
 def filament_pairs(factory, now: float, n_r: int, omega_rows: np.ndarray, r_norm_all: np.ndarray):
     """(rows, table) for the alive filaments in list order (render.py:3606-3638).  The per-row
     scalars are evaluated exactly as `lifecycle.rasterize_entities` does (f32 centre under NumPy's
-    weak-scalar promotion, f64 radial weight through math.exp)."""
-    rows_all, recs = [], []
-    two_pi32 = np.float32(_TWO_PI)
+    weak-scalar promotion, f64 radial weight through math.exp); the per-entity scalars are computed
+    in a Python loop, everything per (entity, row) in one vector pass over all pairs."""
+    rows_l, rw_l, om_l, counts = [], [], [], []
+    src, age32, inv2s, sc_d, sc_t = [], [], [], [], []
     for e in factory.alive_entities:
         age = now - e.birth_time
         if e.density_factor(age) < FILAMENT_DEATH_THRESHOLD:
+            continue
+        _, rows, r_w, om = _filament_static(e, n_r, omega_rows, r_norm_all)
+        if len(rows) == 0:
             continue
         s0 = max(e.blob_sigma_phi0, 1e-6)
         sigma_phi = s0 + e.alpha_shear * age
@@ -57,31 +75,32 @@ def filament_pairs(factory, now: float, n_r: int, omega_rows: np.ndarray, r_norm
         amp_t = e.blob_peak_temp * s0 / sigma_phi
         born = min(age / FILAMENT_BIRTH_FADE_DUR, 1.0) if FILAMENT_BIRTH_FADE_DUR > 0 else 1.0
         cool = math.exp(-age / e.tau_cool) if e.tau_cool > 0 else 1.0
-        scale_d = amp_d * born * cool
-        scale_t = amp_t * born * cool
-        inv_2s_phi = 0.5 / (sigma_phi * sigma_phi)
-        sigma_r = max(e.blob_sigma_r, 1e-6)
-        inv_2s_r = 0.5 / (sigma_r * sigma_r)
-        rows = e.row_indices[(e.row_indices >= 0) & (e.row_indices < n_r)]
-        if len(rows) == 0:
-            continue
-        r_w = np.array([math.exp(-(r_norm_all[ri] - e.blob_base_r) ** 2 * inv_2s_r) for ri in rows])
-        center = (np.float32(e.source_phi) - omega_rows[rows] * np.float32(age)) % two_pi32   # f32, as the scalar code
-        rec = np.empty(len(rows), dtype=FIL_DTYPE)
-        rec["center"] = center.astype(np.float64)
-        rec["inv_2s_phi"] = inv_2s_phi
-        rec["coef_d"] = scale_d * r_w
-        rec["coef_t"] = scale_t * r_w
-        rows_all.append(rows)
-        recs.append(rec)
-    if not recs:
+        rows_l.append(rows); rw_l.append(r_w); om_l.append(om); counts.append(len(rows))
+        src.append(e.source_phi); age32.append(age)
+        inv2s.append(0.5 / (sigma_phi * sigma_phi))
+        sc_d.append(amp_d * born * cool)
+        sc_t.append(amp_t * born * cool)
+    if not counts:
         return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=FIL_DTYPE)
-    return np.concatenate(rows_all).astype(np.int64), np.concatenate(recs)
+    counts = np.asarray(counts)
+    rows = np.concatenate(rows_l)
+    r_w = np.concatenate(rw_l)
+    om = np.concatenate(om_l)
+    rep = lambda v, dt: np.repeat(np.asarray(v, dtype=dt), counts)
+    # (f32(source_phi) - omega[row] * f32(age)) % f32(2 pi): the same f32 operations, elementwise
+    center = (rep(src, np.float32) - om * rep(age32, np.float32)) % np.float32(_TWO_PI)
+    rec = np.empty(len(rows), dtype=FIL_DTYPE)
+    rec["center"] = center.astype(np.float64)
+    rec["inv_2s_phi"] = rep(inv2s, np.float64)
+    rec["coef_d"] = rep(sc_d, np.float64) * r_w
+    rec["coef_t"] = rep(sc_t, np.float64) * r_w
+    return rows, rec
 
 
 def rolled_pairs(factories: dict, now: float, n_r: int, n_phi: int, omega_rows: np.ndarray, pool):
     """(rows, table) for RT spikes then hotspots (render.py:3640-3649)."""
-    rows_all, recs = [], []
+    rows_l, om_l, off_l, counts = [], [], [], []
+    age32, alpha32, plane, stride_l = [], [], [], []
     for key in ("rt_spike", "hotspot"):
         factory = factories.get(key)
         if factory is None:
@@ -90,25 +109,31 @@ def rolled_pairs(factories: dict, now: float, n_r: int, n_phi: int, omega_rows: 
             alpha = e.fade_factor(now)
             if alpha <= 0:
                 continue
-            age = now - e.birth_time
             off, stride = pool.offset_of(e)
-            k_idx = np.nonzero((e.row_indices >= 0) & (e.row_indices < n_r))[0]
-            rows = e.row_indices[k_idx]
+            c = getattr(e, "_pair_static", None)
+            if c is None or c[0] != (n_r, n_phi):
+                k_idx = np.nonzero((e.row_indices >= 0) & (e.row_indices < n_r))[0]
+                rows = e.row_indices[k_idx].astype(np.int64)
+                c = ((n_r, n_phi), rows, omega_rows[rows], k_idx.astype(np.int64) * n_phi)
+                e._pair_static = c
+            _, rows, om, rel = c
             if len(rows) == 0:
                 continue
-            # int(age * omega[row] / (2 pi) * n_phi) with the f32 arithmetic of np.float32 scalars
-            shift = (np.float32(age) * omega_rows[rows] / np.float32(_TWO_PI) * np.float32(n_phi)).astype(np.int64)
-            rec = np.empty(len(rows), dtype=ROL_DTYPE)
-            rec["offset"] = off + k_idx.astype(np.int64) * n_phi
-            rec["shift"] = shift
-            rec["plane"] = _PLANE[key]
-            rec["alpha"] = np.float32(alpha)
-            rec["stride"] = stride
-            rows_all.append(rows)
-            recs.append(rec)
-    if not recs:
+            rows_l.append(rows); om_l.append(om); off_l.append(off + rel); counts.append(len(rows))
+            age32.append(now - e.birth_time); alpha32.append(alpha); plane.append(_PLANE[key]); stride_l.append(stride)
+    if not counts:
         return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=ROL_DTYPE)
-    return np.concatenate(rows_all).astype(np.int64), np.concatenate(recs)
+    counts = np.asarray(counts)
+    rows = np.concatenate(rows_l)
+    rep = lambda v, dt: np.repeat(np.asarray(v, dtype=dt), counts)
+    rec = np.empty(len(rows), dtype=ROL_DTYPE)
+    rec["offset"] = np.concatenate(off_l)
+    # int(age * omega[row] / (2 pi) * n_phi) with the f32 arithmetic of np.float32 scalars
+    rec["shift"] = (rep(age32, np.float32) * np.concatenate(om_l) / np.float32(_TWO_PI) * np.float32(n_phi)).astype(np.int64)
+    rec["plane"] = rep(plane, np.int32)
+    rec["alpha"] = rep(alpha32, np.float32)
+    rec["stride"] = rep(stride_l, np.int32)
+    return rows, rec
 
 
 def to_csr(rows: np.ndarray, table: np.ndarray, n_r: int):

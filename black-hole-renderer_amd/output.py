@@ -59,9 +59,11 @@ class FrameSink:
     ``submit(path)`` quantises the renderer's FINAL layer on the device, starts the copy into a pinned
     host slot and returns; worker threads encode and write.  ``drain()`` waits for the files."""
 
-    def __init__(self, renderer, slots: int = 8, workers: int = 0, level: int = VIDEO_LEVEL):
+    def __init__(self, renderer, slots: int = 0, workers: int = 0, level: int = VIDEO_LEVEL):
         if workers <= 0:
             workers = max(1, min(16, len(os.sched_getaffinity(0)) - 1))
+        if slots <= 0:
+            slots = workers + 4        # every encoder busy plus a few frames of slack for the renderer
         self._lib = _lib.load()
         self._sink = C.c_void_p()
         self._renderer = renderer          # keeps the context alive

@@ -44,5 +44,5 @@ def test_sink_reports_write_errors(tmp_path):
     assert sink.drain()[0] == 1
     sink.close()
     with pytest.raises(ValueError):
-        FrameSink(r, slots=0)
+        FrameSink(r, slots=1000)
     r.close()
