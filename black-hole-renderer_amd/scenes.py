@@ -68,6 +68,17 @@ SCENES = {
         step_size=0.1, r_max=10.0, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=20.0, anti_alias="lod_radius",
         aa_strength=1.5)),
     # configs[3] step size, camera off-axis, ragged size (not a multiple of the 8x8 tile)
+    # camera on the polar axis: build_camera's fallback basis (render.py:108-111), disk seen face-on
+    "polar": dict(width=96, height=64, cam_pos=[0, 0, 8], fov=70, kw=dict(
+        step_size=0.1, r_max=10.0, r_disk_inner=2.0, r_disk_outer=6.0, disk_tilt=0.0, anti_alias="lod_radius")),
+    # camera between the disk's inner and outer radius, just above the plane: several crossings per ray
+    "inside": dict(width=120, height=80, cam_pos=[3.2, 0.5, 0.12], fov=100, kw=dict(
+        step_size=0.1, r_max=10.0, r_disk_inner=2.0, r_disk_outer=9.0, disk_tilt=3.0, anti_alias="disabled")),
+    # narrower than one bloom tap (R = int(0.02 W) = 0) and shorter than a tile
+    "sliver": dict(width=40, height=3, cam_pos=[6, 0, 0.5], fov=90, kw=dict(
+        step_size=0.1, r_max=10.0, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=0.0, anti_alias="disabled")),
+    "one_pixel": dict(width=1, height=1, cam_pos=[6, 0, 0.5], fov=20, kw=dict(
+        step_size=0.1, r_max=10.0, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=0.0, anti_alias="lod_radius")),
     "fine_ragged": dict(width=203, height=117, cam_pos=[4, 3, 1.5], fov=75, kw=dict(
         step_size=0.05, r_max=10.0, r_disk_inner=2.0, r_disk_outer=8.0, disk_tilt=5.0, anti_alias="disabled")),
 }
