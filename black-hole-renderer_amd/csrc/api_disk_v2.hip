@@ -51,18 +51,40 @@ extern "C" int32_t bhr_disk_v2_eval(bhr_ctx *ctx, const bhr_disk_v2_params *p, i
 
 extern "C" int32_t bhr_set_disk_source(bhr_ctx *ctx, int32_t source, const bhr_disk_v2_params *p, double norm_shear,
                                        double norm_hotspot, double t_peak) {
-    if (!ctx || (source != BHR_DISK_TEXTURE && source != BHR_DISK_V2)) return bhr_fail(BHR_ERR_INVALID, "bhr_set_disk_source: bad argument");
+    if (!ctx || (source != BHR_DISK_TEXTURE && source != BHR_DISK_V2 && source != BHR_DISK_V2_VOLUME))
+        return bhr_fail(BHR_ERR_INVALID, "bhr_set_disk_source: bad argument");
     BHR_HIP(hipSetDevice(ctx->cfg.device));
-    if (source == BHR_DISK_V2) {
+    if (source != BHR_DISK_TEXTURE) {
         if (!p || !(norm_shear > 0.0) || !(norm_hotspot > 0.0) || !(t_peak > 0.0))
             return bhr_fail(BHR_ERR_INVALID, "bhr_set_disk_source: Disk V2 needs parameters and positive normalisation constants");
+        if (!(p->r_out > p->r_in) || !(p->r_in > 0.0) || !(p->h0 > 0.0) || p->shear_components < 0 ||
+            p->shear_components > BHR_DV2_MAX_TERMS || p->hotspot_count < 0 || p->hotspot_count > BHR_DV2_MAX_TERMS)
+            return bhr_fail(BHR_ERR_INVALID, "bhr_set_disk_source: inconsistent Disk V2 parameters");
         if (!ctx->d_dv2_params) BHR_HIP(hipMalloc((void **)&ctx->d_dv2_params, sizeof(bhr_disk_v2_params)));
         BHR_HIP(hipMemcpyAsync(ctx->d_dv2_params, p, sizeof(*p), hipMemcpyHostToDevice, ctx->stream));
         BHR_HIP(hipStreamSynchronize(ctx->stream));
         ctx->dv2_norm[0] = norm_shear;
         ctx->dv2_norm[1] = norm_hotspot;
         ctx->dv2_norm[2] = t_peak;
+        // bounding slab of the volume: H(r) = h0 r (r / r_in)^beta is monotonic, its maximum sits at an end
+        const double h_in = p->h0 * p->r_in, h_out = p->h0 * p->r_out * pow(p->r_out / p->r_in, p->beta_h);
+        ctx->vol_opts[2] = h_in > h_out ? h_in : h_out;
+        ctx->vol_opts[3] = sqrt(p->r_out * p->r_out + ctx->vol_opts[2] * ctx->vol_opts[2]);
+        if (ctx->vol_substeps == 0) {   // options never set: defaults
+            ctx->vol_opts[0] = 4.0;
+            ctx->vol_opts[1] = 1.0;
+            ctx->vol_substeps = 2;
+        }
     }
     ctx->disk_source = source;
+    return BHR_OK;
+}
+
+extern "C" int32_t bhr_set_disk_volume_options(bhr_ctx *ctx, double absorption, double grazing_gain, int32_t substeps) {
+    if (!ctx || !(absorption >= 0.0) || !(grazing_gain >= 0.0) || substeps < 1 || substeps > 16)
+        return bhr_fail(BHR_ERR_INVALID, "bhr_set_disk_volume_options: absorption/grazing_gain must be >= 0, substeps in 1..16");
+    ctx->vol_opts[0] = absorption;
+    ctx->vol_opts[1] = grazing_gain;
+    ctx->vol_substeps = substeps;
     return BHR_OK;
 }

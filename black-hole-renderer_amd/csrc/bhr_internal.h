@@ -22,6 +22,8 @@
 #define BHR_DISK_RADIAL_BRIGHTNESS_MIN 0.2f
 #define BHR_DISK_RADIAL_BRIGHTNESS_MAX 8.0f
 
+#define BHR_VOLUME_OPAQUE 0.9999f   // finite-thickness disk: accumulated opacity at which a ray stops sampling
+
 #define BHR_PI_F 3.14159274101257324f      // (float)pi
 #define BHR_TWO_PI_F 6.28318548202514648f  // (float)(2*pi)
 
@@ -55,6 +57,8 @@ struct BhrMarchArgs {
     unsigned int *queue;     // persistent-wave work counter (zeroed before launch)
     const bhr_disk_v2_params *dv2;   // non-null: analytic Disk V2 source instead of the texture
     double dv2_norm_shear, dv2_norm_hotspot, dv2_t_peak;
+    double vol_absorption, vol_grazing_gain, vol_h_max, vol_r_max;   // finite-thickness Disk V2
+    int32_t vol_substeps;
     int32_t n_tiles;         // 8x8 pixel tiles in the row block
     int32_t tiles_x;
 };
@@ -99,6 +103,8 @@ struct bhr_ctx {
     int32_t disk_source;
     bhr_disk_v2_params *d_dv2_params;
     double dv2_norm[3];        // max|raw shear|, max|raw hotspot| on the reference grid, peak T_mid
+    double vol_opts[4];        // absorption Ca, grazing gain kg, max half thickness, max spherical radius of the volume
+    int32_t vol_substeps;
 
     // frame buffers for rows [row0,row1)
     float *d_bg, *d_disk;      // (rows, W, 3)

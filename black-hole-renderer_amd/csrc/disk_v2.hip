@@ -40,17 +40,8 @@ __global__ __launch_bounds__(256) void disk_v2_kernel(bhr_disk_v2_params p, cons
             case BHR_DV2_OMEGA: v = omega_field(ri, p); break;
             case BHR_DV2_RHO_MID: v = rho_mid(ri, p); break;
             case BHR_DV2_T_MID: v = t_mid(ri, p); break;
-            case BHR_DV2_RHO: {
-                double th = fmax(half_thickness(ri, p), DBL_EPSILON), q = zi / th;
-                v = rho_mid(ri, p) * exp(-0.5 * (q * q)) * vertical_weight(ri, zi, p);
-                if (!volume_mask(ri, zi, p)) v = 0.0;
-            } break;
-            case BHR_DV2_T: {
-                double th = fmax(half_thickness(ri, p), DBL_EPSILON);
-                double vf = fmin(fmax(1.0 - 0.25 * fabs(zi) / th, 0.0), 1.0);
-                v = t_mid(ri, p) * vf * vertical_weight(ri, zi, p);
-                if (!volume_mask(ri, zi, p)) v = 0.0;
-            } break;
+            case BHR_DV2_RHO: v = rho_field(ri, zi, p); break;
+            case BHR_DV2_T: v = t_field(ri, zi, p); break;
             case BHR_DV2_F_MODE: v = mode_factor(ri, ph, p); break;
             case BHR_DV2_F_SHEAR: v = raw_shear(ri, ph, p); m0 = fabs(v); break;
             case BHR_DV2_F_HOTSPOT: v = raw_hotspot(ri, ph, p); m0 = fabs(v); break;

@@ -46,6 +46,19 @@ __device__ __forceinline__ double t_mid(double r, const bhr_disk_v2_params &p) {
     double t = p.temp_scale * pow(safe_r / p.r_in, -0.75) * pow(inner, 0.25) * radial_weight(r, p);
     return r <= p.r_in ? 0.0 : t;
 }
+// rho(r, z) = rho_mid exp(-z^2 / 2H^2) W_z inside the volume, 0 outside   (physical_fields.py:119-160)
+__device__ __forceinline__ double rho_field(double r, double z, const bhr_disk_v2_params &p) {
+    double th = fmax(half_thickness(r, p), DBL_EPSILON), q = z / th;
+    double v = rho_mid(r, p) * exp(-0.5 * (q * q)) * vertical_weight(r, z, p);
+    return volume_mask(r, z, p) ? v : 0.0;
+}
+// T(r, z) = T_mid clip(1 - |z| / 4H, 0, 1) W_z inside the volume, 0 outside   (physical_fields.py:163-205)
+__device__ __forceinline__ double t_field(double r, double z, const bhr_disk_v2_params &p) {
+    double th = fmax(half_thickness(r, p), DBL_EPSILON);
+    double vf = fmin(fmax(1.0 - 0.25 * fabs(z) / th, 0.0), 1.0);
+    double v = t_mid(r, p) * vf * vertical_weight(r, z, p);
+    return volume_mask(r, z, p) ? v : 0.0;
+}
 __device__ __forceinline__ double log_radius(double r, const bhr_disk_v2_params &p) { return log(fmax(r, p.r_in) / p.r_in); }
 __device__ __forceinline__ double wrapped_dphi(double phi, double c) { return atan2(sin(phi - c), cos(phi - c)); }
 

@@ -270,16 +270,9 @@ __device__ __forceinline__ V3 apply_g_factor(const BhrMarchArgs &a, V3 base_colo
 // the compose kernel's (render.py:3192-3194, 3243-3257): t = clamp(T / T_peak), T_K = T_min + t (T_max -
 // T_min), rgb = blackbody(T_K) sqrt(t) with blue <= red, alpha = clamp(rho).  The reference never wired
 // disk_v2 into its renderer (docs/design_ad_v2.md Phase 4), so this mapping is this build's choice.
-__device__ __forceinline__ float4 disk_v2_rgba(const BhrMarchArgs &a, float hit_x, float hit_y) {
-    const bhr_disk_v2_params &p = *a.dv2;
-    double r = sqrt((double)hit_x * hit_x + (double)hit_y * hit_y);
-    double phi = atan2((double)hit_y, (double)hit_x) + (double)a.t_offset * dv2::omega_field(r, p);
-    double F = dv2::structure_total(r, phi, p, a.dv2_norm_shear, a.dv2_norm_hotspot);
-    double t = fmin(fmax(dv2::t_mid(r, p) * F / a.dv2_t_peak, 0.0), 1.0);
-    double rho = fmin(fmax(dv2::rho_mid(r, p) * F, 0.0), 1.0);
+__device__ __forceinline__ V3 disk_v2_color(float tf) {
     const float t_factor = (BHR_DISK_COLOR_TEMPERATURE - 4500.0f) / (6500.0f - 2700.0f);
     const float T_min = 2000.0f + t_factor * 1000.0f, T_max = 9000.0f + t_factor * 3000.0f;
-    float tf = (float)t;
     float tk = (T_min + tf * (T_max - T_min)) / 100.0f;
     float cr = 1.0f, cg, cb = 1.0f;   // _color_temp_to_tint (render.py:2407-2437)
     if (tk > 66.0f) cr = fminf(fmaxf(1.292936f * powf(fmaxf(tk - 60.0f, 0.0001f), -0.1332047592f), 0.0f), 1.0f);
@@ -288,8 +281,17 @@ __device__ __forceinline__ float4 disk_v2_rgba(const BhrMarchArgs &a, float hit_
     if (tk < 66.0f) cb = tk <= 19.0f ? 0.0f : fminf(fmaxf(0.543207f * logf(fmaxf(tk - 10.0f, 0.0001f)) - 1.19625f, 0.0f), 1.0f);
     cb = fminf(cb, cr);
     float lum = fminf(fmaxf(sqrtf(tf), 0.0f), 1.0f);
-    return make_float4(fminf(fmaxf(cr * lum, 0.0f), 1.0f), fminf(fmaxf(cg * lum, 0.0f), 1.0f), fminf(fmaxf(cb * lum, 0.0f), 1.0f),
-                       (float)rho);
+    return mk(fminf(fmaxf(cr * lum, 0.0f), 1.0f), fminf(fmaxf(cg * lum, 0.0f), 1.0f), fminf(fmaxf(cb * lum, 0.0f), 1.0f));
+}
+__device__ __forceinline__ float4 disk_v2_rgba(const BhrMarchArgs &a, float hit_x, float hit_y) {
+    const bhr_disk_v2_params &p = *a.dv2;
+    double r = sqrt((double)hit_x * hit_x + (double)hit_y * hit_y);
+    double phi = atan2((double)hit_y, (double)hit_x) + (double)a.t_offset * dv2::omega_field(r, p);
+    double F = dv2::structure_total(r, phi, p, a.dv2_norm_shear, a.dv2_norm_hotspot);
+    double t = fmin(fmax(dv2::t_mid(r, p) * F / a.dv2_t_peak, 0.0), 1.0);
+    double rho = fmin(fmax(dv2::rho_mid(r, p) * F, 0.0), 1.0);
+    V3 c = disk_v2_color((float)t);
+    return make_float4(c.x, c.y, c.z, (float)rho);
 }
 
 // Shared by both builds: shade one disk crossing and composite it front to back
@@ -312,7 +314,7 @@ struct Pending {
     float dxx, dxy, dyx, dyy;   // DIFF only
     int valid;
 };
-template <bool DIFF, bool DV2>
+template <bool DIFF, int SRC>
 __device__ __forceinline__ void shade_hit(const BhrMarchArgs &a, Shade &sh, float hit_x, float hit_y, V3 to_cam,
                                           float hdx_x, float hdx_y, float hdy_x, float hdy_y) {
     float hit_r = sqrtf(hit_x * hit_x + hit_y * hit_y);
@@ -338,7 +340,7 @@ __device__ __forceinline__ void shade_hit(const BhrMarchArgs &a, Shade &sh, floa
     }
     // DV2 is a separate kernel instantiation: the binary64 model code (and its registers) never
     // touches the texture kernels
-    float4 rgba = DV2 ? disk_v2_rgba(a, hit_x, hit_y)
+    float4 rgba = SRC == 1 ? disk_v2_rgba(a, hit_x, hit_y)
                       : sample_disk_level(a.sc, hit_x, hit_y, a.r_inner, a.r_outer, a.t_offset, lod_i);
     float base_alpha = fminf(rgba.w, 0.999f);
     float disk_alpha = 1.0f - powf(1.0f - base_alpha, BHR_DISK_ALPHA_GAIN);
@@ -352,6 +354,50 @@ __device__ __forceinline__ void shade_hit(const BhrMarchArgs &a, Shade &sh, floa
     sh.accum = mk(fmaf(col.x, wgt, sh.accum.x), fmaf(col.y, wgt, sh.accum.y), fmaf(col.z, wgt, sh.accum.z));
 #endif
     sh.alpha_total = 1.0f - front * (1.0f - disk_alpha);
+}
+
+// Finite-thickness Disk V2 (docs/design_ad_v2.md 4.2-4.3, Phase 3 -- specified there, not implemented in
+// the reference): emission-absorption through the volume |zeta| <= H(r), r_in <= r <= r_out of the tilted
+// disk frame.  One RK4 step = one chord p0 -> p1, cut into vol_substeps pieces sampled at their midpoints:
+//   rho = rho(r, zeta) F(r, phi_adv),  T = T(r, zeta) F,  phi_adv = phi + t_offset Omega(r)   (Phase 2)
+//   alpha_eff = Ca rho [1 + kg (1 - |d.n|)]                                   (grazing-angle gain, 4.3)
+//   opacity of the piece a = 1 - exp(-alpha_eff ds), source colour = black body of T with the g-factor,
+// composited front to back exactly like a surface crossing (render.py:3000-3002), which is the design's
+// L += exp(-tau) j ds, tau += alpha ds with j = alpha S integrated exactly over each piece.
+// Model in binary64 (shared with the field evaluator), compositing in f32.
+__device__ __forceinline__ void volume_segment(const BhrMarchArgs &a, Shade &sh, V3 p0, V3 p1, V3 dir0, float f0, float f1,
+                                               float r0, float r1) {
+    const bhr_disk_v2_params &P = *a.dv2;
+    const double ct = (double)a.cos_t, st = (double)a.sin_t;
+    const double z0 = (double)f0 * ct, z1 = (double)f1 * ct;           // heights above the disk plane
+    const bool near_plane = z0 * z1 < 0.0 || fmin(fabs(z0), fabs(z1)) <= a.vol_h_max;
+    if (!(near_plane && (double)fmaxf(r0, r1) >= P.r_in && (double)fminf(r0, r1) <= a.vol_r_max)) return;
+    if (sh.alpha_total >= BHR_VOLUME_OPAQUE) return;     // what lies behind contributes < 1e-4 of its colour
+    const double ex = (double)p1.x - (double)p0.x, ey = (double)p1.y - (double)p0.y, ez = (double)p1.z - (double)p0.z;
+    const double len = sqrt(ex * ex + ey * ey + ez * ez);
+    if (!(len > 0.0)) return;
+    const double mu = fabs((ez * ct - ey * st) / len);
+    const double ds = len / (double)a.vol_substeps;
+    const V3 to_cam = mk(-dir0.x, -dir0.y, -dir0.z);
+    for (int k = 0; k < a.vol_substeps; ++k) {
+        const double f = ((double)k + 0.5) / (double)a.vol_substeps;
+        const double sx = (double)p0.x + f * ex, sy = (double)p0.y + f * ey, sz = (double)p0.z + f * ez;
+        const double zeta = sz * ct - sy * st;
+        const double yp = sy * ct + sz * st;
+        const double rc = sqrt(sx * sx + yp * yp);
+        if (!dv2::volume_mask(rc, zeta, P)) continue;
+        const double phi = atan2(yp, sx) + (double)a.t_offset * dv2::omega_field(rc, P);
+        const double F = dv2::structure_total(rc, phi, P, a.dv2_norm_shear, a.dv2_norm_hotspot);
+        const double rho = fmax(dv2::rho_field(rc, zeta, P) * F, 0.0);
+        const double t = fmin(fmax(dv2::t_field(rc, zeta, P) * F / a.dv2_t_peak, 0.0), 1.0);
+        const double alpha_eff = a.vol_absorption * rho * (1.0 + a.vol_grazing_gain * (1.0 - mu));
+        const float op = (float)(1.0 - exp(-alpha_eff * ds));
+        if (!(op > 0.0f)) continue;
+        V3 col = apply_g_factor(a, disk_v2_color((float)t), mk((float)sx, (float)sy, (float)sz), (float)rc, to_cam);
+        const float front = 1.0f - sh.alpha_total;
+        sh.accum = mk(sh.accum.x + col.x * op * front, sh.accum.y + col.y * op * front, sh.accum.z + col.z * op * front);
+        sh.alpha_total = 1.0f - front * (1.0f - op);
+    }
 }
 
 // render.py:3008-3018: background through the accumulated opacity + clamped disk layer
@@ -393,7 +439,7 @@ __device__ __forceinline__ V3 pixel_ray(const BhrMarchArgs &a, int i, int j_loca
 // =============================================================================
 // strict build: render.py:2854-3006 operation by operation, 3-D state
 // =============================================================================
-template <bool DIFF, bool DV2 = false>
+template <bool DIFF, int SRC = 0>
 struct Ray {
     V3 p, d;
     float m15L2;   // -1.5 * L2
@@ -515,7 +561,9 @@ struct Ray {
         const bool escaped = !captured && (rn > a.r_esc || aff > a.max_affine);
         const bool alive = !captured && !escaped;
         float f_new = np.z - np.y * a.tan_t;
-        if (alive && f_old * f_new < 0) {
+        if (SRC == 2) {
+            if (alive) volume_segment(a, sh, p, np, d, f_old, f_new, r, rn);
+        } else if (alive && f_old * f_new < 0) {
             float t_frac = div_rn(f_old, f_old - f_new + 1e-8f);
             float hx = p.x + t_frac * (np.x - p.x);
             float hy = p.y + t_frac * (np.y - p.y);
@@ -547,7 +595,7 @@ struct Ray {
     }
 
     __device__ __forceinline__ void shade_pending(const BhrMarchArgs &a) {
-        shade_hit<DIFF, DV2>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
+        shade_hit<DIFF, SRC>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
         pend.valid = 0;
     }
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, esc, sh); }
@@ -567,7 +615,7 @@ struct Ray {
 // pair coupled through the projection term of the Jacobian and an out-of-plane component that
 // sees only the isotropic term:  J d = c (d - 5 s (s.d)/r^2).
 // =============================================================================
-template <bool DIFF, bool DV2 = false>
+template <bool DIFF, int SRC = 0>
 struct Ray {
     float u, w, du, dw;   // position / direction along (g1, g2)
     float m15L2;          // -1.5 * L2
@@ -709,7 +757,9 @@ struct Ray {
         const bool alive = !captured && !escaped;
         float f_new = Bn * nw;
         bool redo = false;
-        if (alive && f_old * f_new < 0) {
+        if (SRC == 2) {
+            if (alive) volume_segment(a, sh, to3d(u, w), to3d(nu, nw), to3d(du, dw), f_old, f_new, q_rcp(ir), r2n * q_rsq(r2n));
+        } else if (alive && f_old * f_new < 0) {
             float t_frac = f_old / (f_old - f_new + 1e-8f);
             float hu = fmaf(t_frac, nu - u, u), hw = fmaf(t_frac, nw - w, w);
             float hx = fmaf(hu, g1.x, hw * g2.x);
@@ -761,7 +811,7 @@ struct Ray {
     }
 
     __device__ __forceinline__ void shade_pending(const BhrMarchArgs &a) {
-        shade_hit<DIFF, DV2>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
+        shade_hit<DIFF, SRC>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
         pend.valid = 0;
     }
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, to3d(du, dw), sh); }
@@ -782,7 +832,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // ring) evenly.  An XCD-banded remap was measured and rejected (-13 %: the kernel is VALU
 // bound, texture traffic is negligible, and bands of rows differ in cost).
 // ---------------------------------------------------------------------------
-template <bool DIFF, bool DV2 = false>
+template <bool DIFF, int SRC = 0>
 __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     const int lane = threadIdx.x & 63;
     // one 8x8 tile per wave, tiles in row-major order; blockDim.x / 64 waves per block
@@ -792,7 +842,7 @@ __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     const int j = ty * 8 + (lane >> 3);
     const bool valid = tile < a.n_tiles && i < a.width && j < a.rows;
 
-    Ray<DIFF, DV2> ray;
+    Ray<DIFF, SRC> ray;
     ray.init(a, valid ? i : 0, valid ? j : 0);
     if (!valid) ray.done = 4;
     unsigned int executed = 0;
@@ -928,7 +978,7 @@ int32_t bhr_selftest_strict(bhr_ctx *ctx, unsigned long long *d_out4) {
 
 int32_t BHR_MARCH_RESOURCES(int32_t *vgprs, int32_t *lds, int32_t diff) {
     hipFuncAttributes at;
-    const void *f = diff ? (const void *)march_tile_kernel<true, false> : (const void *)march_tile_kernel<false, false>;
+    const void *f = diff ? (const void *)march_tile_kernel<true, 0> : (const void *)march_tile_kernel<false, 0>;
     BHR_HIP(hipFuncGetAttributes(&at, f));
     *vgprs = at.numRegs;
     *lds = (int32_t)at.sharedSizeBytes;
@@ -997,7 +1047,12 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     const int slot = ctx->cur_slot;
     a.ray_steps = slot >= 0 ? ctx->d_steps_ring + slot : ctx->d_ray_steps;
     a.queue = ctx->d_queue;
-    a.dv2 = ctx->disk_source == BHR_DISK_V2 ? ctx->d_dv2_params : nullptr;
+    a.dv2 = ctx->disk_source != BHR_DISK_TEXTURE ? ctx->d_dv2_params : nullptr;
+    a.vol_absorption = ctx->vol_opts[0];
+    a.vol_grazing_gain = ctx->vol_opts[1];
+    a.vol_h_max = ctx->vol_opts[2];
+    a.vol_r_max = ctx->vol_opts[3];
+    a.vol_substeps = ctx->vol_substeps;
     a.dv2_norm_shear = ctx->dv2_norm[0];
     a.dv2_norm_hotspot = ctx->dv2_norm[1];
     a.dv2_t_peak = ctx->dv2_norm[2];
@@ -1020,15 +1075,17 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         if (bt != 64 && bt != 128 && bt != 256) bt = 256;
         const int wpb = bt / 64;
         dim3 grid((a.n_tiles + wpb - 1) / wpb), block(bt);
-        if (a.dv2) {   // analytic Disk V2 source: its own instantiations
+        if (ctx->disk_source == BHR_DISK_V2_VOLUME) {   // finite-thickness Disk V2: no texture footprint to track
+            hipLaunchKernelGGL((march_tile_kernel<false, 2>), grid, block, 0, ctx->stream, a);
+        } else if (a.dv2) {   // analytic Disk V2 source: its own instantiations
             if (want_diff)
-                hipLaunchKernelGGL((march_tile_kernel<true, true>), grid, block, 0, ctx->stream, a);
+                hipLaunchKernelGGL((march_tile_kernel<true, 1>), grid, block, 0, ctx->stream, a);
             else
-                hipLaunchKernelGGL((march_tile_kernel<false, true>), grid, block, 0, ctx->stream, a);
+                hipLaunchKernelGGL((march_tile_kernel<false, 1>), grid, block, 0, ctx->stream, a);
         } else if (want_diff) {
-            hipLaunchKernelGGL((march_tile_kernel<true, false>), grid, block, 0, ctx->stream, a);
+            hipLaunchKernelGGL((march_tile_kernel<true, 0>), grid, block, 0, ctx->stream, a);
         } else {
-            hipLaunchKernelGGL((march_tile_kernel<false, false>), grid, block, 0, ctx->stream, a);
+            hipLaunchKernelGGL((march_tile_kernel<false, 0>), grid, block, 0, ctx->stream, a);
         }
     } else {
         // enough resident waves to fill the chip; every wave drains the queue and exits

@@ -278,19 +278,27 @@ class HipRenderer:
         return out
 
     # ------------------------------------------------------------------ analytic disk source
-    def use_disk_v2(self, params=None, structure_params=None, seed: int = 42) -> None:
-        """Shade disk hits from the Disk V2 model inside the march kernel instead of the texture
-        (include/bhr_disk_v2.h: bhr_set_disk_source).  Pass ``params=None`` to go back to the texture."""
+    def use_disk_v2(self, params=None, structure_params=None, seed: int = 42, volume: bool = False,
+                    absorption: float = 4.0, grazing_gain: float = 1.0, substeps: int = 2) -> None:
+        """Shade the disk from the Disk V2 model inside the march kernel instead of the texture
+        (include/bhr_disk_v2.h: bhr_set_disk_source).  ``volume=False``: the model's mid-plane fields at
+        every plane crossing; ``volume=True``: the finite-thickness emission-absorption integral of
+        docs/design_ad_v2.md 4.3 (absorption coefficient per unit density, grazing-angle gain, pieces per
+        RK4 step).  Pass ``params=None`` to go back to the texture."""
         from . import disk_v2 as dv
         lib = self._lib
         lib.bhr_set_disk_source.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double]
         lib.bhr_set_disk_source.restype = C.c_int32
+        lib.bhr_set_disk_volume_options.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int32]
+        lib.bhr_set_disk_volume_options.restype = C.c_int32
         if params is None:
             _lib.check(lib.bhr_set_disk_source(self._ctx, 0, None, 0.0, 0.0, 0.0))
             self._dv2 = None
             return
         cp, m_sh, m_hs, t_peak = dv.reference_norms(params, structure_params, seed, ctx=self._ctx)
-        _lib.check(lib.bhr_set_disk_source(self._ctx, 1, C.byref(cp), m_sh, m_hs, t_peak))
+        if volume:
+            _lib.check(lib.bhr_set_disk_volume_options(self._ctx, absorption, grazing_gain, substeps))
+        _lib.check(lib.bhr_set_disk_source(self._ctx, 2 if volume else 1, C.byref(cp), m_sh, m_hs, t_peak))
         self._dv2 = (cp, m_sh, m_hs, t_peak)
 
     # ------------------------------------------------------------------ rendering

@@ -61,8 +61,20 @@ BHR_API int32_t bhr_disk_v2_eval(bhr_ctx *ctx, const bhr_disk_v2_params *params,
  * structure sums on a reference grid (bhr_disk_v2_eval(..., max_out)), t_peak the maximum of T_mid(r). */
 #define BHR_DISK_TEXTURE 0
 #define BHR_DISK_V2 1
+/* BHR_DISK_V2_VOLUME: the finite-thickness disk of docs/design_ad_v2.md 4.2-4.3 (Phase 2 advection + Phase 3
+ * emission-absorption integral; specified in the reference's design, not implemented there).  Every RK4 step
+ * that passes through the volume |zeta| <= H(r), r_in <= r <= r_out of the tilted disk frame is cut into
+ * `substeps` pieces; a piece at density rho, with direction cosine mu to the disk normal, has opacity
+ * 1 - exp(-absorption * rho * (1 + grazing_gain * (1 - mu)) * ds) and the black-body colour of T(r, zeta) F
+ * under the g-factor; pieces composite front to back like surface crossings (csrc/march.hip:
+ * volume_segment); a ray stops sampling once its accumulated opacity reaches 0.9999.
+ * Options are set with bhr_set_disk_volume_options before bhr_set_disk_source. */
+#define BHR_DISK_V2_VOLUME 2
 BHR_API int32_t bhr_set_disk_source(bhr_ctx *ctx, int32_t source, const bhr_disk_v2_params *params, double norm_shear,
                                     double norm_hotspot, double t_peak);
+
+/* Defaults: absorption 4.0 per unit length at rho = 1, grazing_gain 1.0, substeps 2 (1..16). */
+BHR_API int32_t bhr_set_disk_volume_options(bhr_ctx *ctx, double absorption, double grazing_gain, int32_t substeps);
 
 #ifdef __cplusplus
 }

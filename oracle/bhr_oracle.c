@@ -427,6 +427,211 @@ ORACLE_API void oracle_eval_noise(const f32 *coords, int64_t n, int32_t mode, in
     }
 }
 
+/* ---- Disk V2 (reference: disk_v2/geometry.py, physical_fields.py, structure_modulations.py) ------
+ * Scalar binary64 restatement, pinned by tests/golden/disk_v2.npz (made from the reference package).
+ * The random tables of shear_modulation / hotspot_modulation are drawn by the caller. */
+#define DV2_MAX_TERMS 32
+typedef struct {
+    double r_in, r_out, h0, beta_h, rho_power, temp_scale, omega_scale, edge_softness;
+    double mode1_strength, mode2_strength, shear_strength, hotspot_strength;
+    double hotspot_phi_sigma, hotspot_logr_sigma, hotspot_inner_bias;
+    int32_t shear_components, hotspot_count;
+    int32_t shear_phi_freq[DV2_MAX_TERMS], shear_logr_freq[DV2_MAX_TERMS];
+    double shear_phase[DV2_MAX_TERMS];
+    double hotspot_phase[DV2_MAX_TERMS], hotspot_log_r[DV2_MAX_TERMS], hotspot_weight[DV2_MAX_TERMS];
+} oracle_dv2_params;
+
+#define DV2_EPS 2.220446049250313e-16
+static double dv2_smoothstep(double e0, double e1, double x)       /* geometry.py:15-47 */
+{
+    double t = fmin(fmax((x - e0) / (e1 - e0), 0.0), 1.0);
+    return t * t * (3.0 - 2.0 * t);
+}
+static double dv2_H(double r, const oracle_dv2_params *p)          /* geometry.py:50-77 */
+{
+    double safe_r = fmax(r, p->r_in);
+    return p->h0 * safe_r * pow(safe_r / p->r_in, p->beta_h);
+}
+static int dv2_mask_r(double r, const oracle_dv2_params *p) { return r >= p->r_in && r <= p->r_out; }   /* 80-113 */
+static double dv2_W_r(double r, const oracle_dv2_params *p)        /* geometry.py:116-185 */
+{
+    double span = p->r_out - p->r_in;
+    double soft = fmax(span * p->edge_softness, DV2_EPS);
+    double inner = dv2_smoothstep(p->r_in, p->r_in + soft, r);
+    double outer = 1.0 - dv2_smoothstep(p->r_out - soft, p->r_out, r);
+    return (r <= p->r_in || r >= p->r_out) ? 0.0 : inner * outer;
+}
+static double dv2_W_z(double r, double z, const oracle_dv2_params *p)   /* geometry.py:188-235 */
+{
+    double th = fmax(dv2_H(r, p), DV2_EPS);
+    double w = 1.0 - dv2_smoothstep(0.0, 1.0, fabs(z) / th);
+    return dv2_mask_r(r, p) ? w : 0.0;
+}
+static int dv2_mask_vol(double r, double z, const oracle_dv2_params *p) { return dv2_mask_r(r, p) && fabs(z) <= dv2_H(r, p); }
+static double dv2_omega(double r, const oracle_dv2_params *p)      /* physical_fields.py:21-49 */
+{
+    return p->omega_scale * pow(fmax(r, p->r_in) / p->r_in, -1.5);
+}
+static double dv2_rho_mid(double r, const oracle_dv2_params *p)    /* physical_fields.py:52-79 */
+{
+    return pow(fmax(r, p->r_in) / p->r_in, -p->rho_power) * dv2_W_r(r, p);
+}
+static double dv2_t_mid(double r, const oracle_dv2_params *p)      /* physical_fields.py:82-116 */
+{
+    double safe_r = fmax(r, p->r_in);
+    double inner = fmax(1.0 - sqrt(p->r_in / safe_r), 0.0);
+    double t = p->temp_scale * pow(safe_r / p->r_in, -0.75) * pow(inner, 0.25) * dv2_W_r(r, p);
+    return r <= p->r_in ? 0.0 : t;
+}
+static double dv2_rho(double r, double z, const oracle_dv2_params *p)   /* physical_fields.py:119-160 */
+{
+    double th = fmax(dv2_H(r, p), DV2_EPS), q = z / th;
+    double v = dv2_rho_mid(r, p) * exp(-0.5 * (q * q)) * dv2_W_z(r, z, p);
+    return dv2_mask_vol(r, z, p) ? v : 0.0;
+}
+static double dv2_T(double r, double z, const oracle_dv2_params *p)     /* physical_fields.py:163-205 */
+{
+    double th = fmax(dv2_H(r, p), DV2_EPS);
+    double vf = fmin(fmax(1.0 - 0.25 * fabs(z) / th, 0.0), 1.0);
+    double v = dv2_t_mid(r, p) * vf * dv2_W_z(r, z, p);
+    return dv2_mask_vol(r, z, p) ? v : 0.0;
+}
+static double dv2_logr(double r, const oracle_dv2_params *p) { return log(fmax(r, p->r_in) / p->r_in); }
+static double dv2_raw_shear(double r, double phi, const oracle_dv2_params *p)   /* structure_modulations.py:145-207 */
+{
+    double lr = dv2_logr(r, p), s = 0.0, amp = 1.0;
+    for (int k = 0; k < p->shear_components; ++k) {
+        double pf = (double)p->shear_phi_freq[k], lf = (double)p->shear_logr_freq[k], ph = p->shear_phase[k];
+        s += amp * cos(pf * phi + lf * lr + ph);
+        s += 0.6 * amp * sin((pf + 1.0) * phi - (lf + 0.5) * lr + 0.7 * ph);
+        amp *= 0.5;
+    }
+    return s;
+}
+static double dv2_raw_hotspot(double r, double phi, const oracle_dv2_params *p) /* structure_modulations.py:210-289 */
+{
+    double lr = dv2_logr(r, p), s = 0.0;
+    for (int k = 0; k < p->hotspot_count; ++k) {
+        double d = phi - p->hotspot_phase[k];
+        double dphi = atan2(sin(d), cos(d));
+        double a = dphi / p->hotspot_phi_sigma, dl = (lr - p->hotspot_log_r[k]) / p->hotspot_logr_sigma;
+        double core = exp(-0.5 * (a * a) - 0.5 * (dl * dl));
+        double b = dphi / (1.8 * p->hotspot_phi_sigma), c = (lr - p->hotspot_log_r[k]) / (1.8 * p->hotspot_logr_sigma);
+        double halo = exp(-0.5 * (b * b) - 0.5 * (c * c));
+        s += p->hotspot_weight[k] * (core - 0.6 * halo);
+    }
+    return s;
+}
+static double dv2_mode(double r, double phi, const oracle_dv2_params *p)        /* structure_modulations.py:95-142 */
+{
+    double lr = dv2_logr(r, p);
+    double raw = p->mode1_strength * cos(phi + 0.35 * lr) + p->mode2_strength * cos(2.0 * phi - 0.65 * lr);
+    return dv2_W_r(r, p) > 0.0 ? 1.0 + raw : 1.0;
+}
+/* structure_modulation (292-334) with the normalisation maxima supplied by the caller */
+static double dv2_structure(double r, double phi, const oracle_dv2_params *p, double norm_shear, double norm_hotspot)
+{
+    if (!(dv2_W_r(r, p) > 0.0)) return 1.0;
+    double sh = 1.0 + p->shear_strength * (norm_shear <= DV2_EPS ? 0.0 : dv2_raw_shear(r, phi, p) / norm_shear);
+    double hs = 1.0 + p->hotspot_strength * (norm_hotspot <= DV2_EPS ? 0.0 : dv2_raw_hotspot(r, phi, p) / norm_hotspot);
+    return dv2_mode(r, phi, p) * sh * hs;
+}
+
+/* field ids follow include/bhr_disk_v2.h: 0 H, 1 mask_r, 2 W_r, 3 W_z, 4 mask_vol, 5 Omega, 6 rho_mid,
+ * 7 T_mid, 8 rho, 9 T, 10 F_mode, 11 raw shear sum, 12 raw hotspot sum, 13 F_total (given norms) */
+ORACLE_API void oracle_dv2_eval(const oracle_dv2_params *p, int32_t field, const double *r, const double *z, const double *phi,
+                                int64_t n, double norm_shear, double norm_hotspot, double *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double ri = r[i], zi = z ? z[i] : 0.0, ph = phi ? phi[i] : 0.0, v = 0.0;
+        switch (field) {
+            case 0: v = dv2_H(ri, p); break;
+            case 1: v = dv2_mask_r(ri, p); break;
+            case 2: v = dv2_W_r(ri, p); break;
+            case 3: v = dv2_W_z(ri, zi, p); break;
+            case 4: v = dv2_mask_vol(ri, zi, p); break;
+            case 5: v = dv2_omega(ri, p); break;
+            case 6: v = dv2_rho_mid(ri, p); break;
+            case 7: v = dv2_t_mid(ri, p); break;
+            case 8: v = dv2_rho(ri, zi, p); break;
+            case 9: v = dv2_T(ri, zi, p); break;
+            case 10: v = dv2_mode(ri, ph, p); break;
+            case 11: v = dv2_raw_shear(ri, ph, p); break;
+            case 12: v = dv2_raw_hotspot(ri, ph, p); break;
+            default: v = dv2_structure(ri, ph, p, norm_shear, norm_hotspot);
+        }
+        out[i] = v;
+    }
+}
+
+/* ---- finite-thickness Disk V2 source (docs/design_ad_v2.md 4.2-4.3; include/bhr_disk_v2.h:
+ * BHR_DISK_V2_VOLUME).  oracle_set_volume(NULL, ...) switches back to the textured thin disk. */
+typedef struct {
+    oracle_dv2_params p;
+    double norm_shear, norm_hotspot, t_peak, absorption, grazing_gain;
+    int32_t substeps, on;
+} volume_t;
+static volume_t g_vol;
+
+ORACLE_API void oracle_set_volume(const oracle_dv2_params *p, double norm_shear, double norm_hotspot, double t_peak,
+                                  double absorption, double grazing_gain, int32_t substeps)
+{
+    g_vol.on = p != NULL;
+    if (!p) return;
+    g_vol.p = *p;
+    g_vol.norm_shear = norm_shear; g_vol.norm_hotspot = norm_hotspot; g_vol.t_peak = t_peak;
+    g_vol.absorption = absorption; g_vol.grazing_gain = grazing_gain; g_vol.substeps = substeps;
+}
+
+/* black-body colour of the normalised temperature t in [0, 1]: the compose kernel's mapping
+ * (render.py:3243-3257) as csrc/march.hip disk_v2_color applies it */
+static v3 dv2_color(float tf)
+{
+    const float t_factor = (DISK_COLOR_TEMPERATURE - 4500.0f) / (6500.0f - 2700.0f);
+    const float T_min = 2000.0f + t_factor * 1000.0f, T_max = 9000.0f + t_factor * 3000.0f;
+    v3 c = color_temp_to_tint(T_min + tf * (T_max - T_min));
+    c.z = fminf(c.z, c.x);
+    float lum = fminf(fmaxf(sqrtf(tf), 0.0f), 1.0f);
+    return v3_make(clampf(c.x * lum, 0.0f, 1.0f), clampf(c.y * lum, 0.0f, 1.0f), clampf(c.z * lum, 0.0f, 1.0f));
+}
+
+/* one RK4 step's chord through the volume; *accum / *alpha_total are composited front to back */
+static void volume_segment(v3 p0, v3 p1, v3 dir0, float tilt_rad, float t_offset, v3 cam_pos, float r_inner, float r_outer,
+                           v3 *accum, float *alpha_total)
+{
+    const oracle_dv2_params *P = &g_vol.p;
+    if (*alpha_total >= 0.9999f) return;   /* BHR_VOLUME_OPAQUE: the ray has stopped sampling */
+    const double ct = (double)cosf(tilt_rad), st = (double)sinf(tilt_rad);
+    const double ex = (double)p1.x - (double)p0.x, ey = (double)p1.y - (double)p0.y, ez = (double)p1.z - (double)p0.z;
+    const double len = sqrt(ex * ex + ey * ey + ez * ez);
+    if (!(len > 0.0)) return;
+    const double mu = fabs((ez * ct - ey * st) / len);
+    const double ds = len / (double)g_vol.substeps;
+    const v3 to_cam = v3_make(-dir0.x, -dir0.y, -dir0.z);
+    for (int k = 0; k < g_vol.substeps; ++k) {
+        const double f = ((double)k + 0.5) / (double)g_vol.substeps;
+        const double sx = (double)p0.x + f * ex, sy = (double)p0.y + f * ey, sz = (double)p0.z + f * ez;
+        const double zeta = sz * ct - sy * st;
+        const double yp = sy * ct + sz * st;
+        const double rc = sqrt(sx * sx + yp * yp);
+        if (!dv2_mask_vol(rc, zeta, P)) continue;
+        const double phi = atan2(yp, sx) + (double)t_offset * dv2_omega(rc, P);
+        const double F = dv2_structure(rc, phi, P, g_vol.norm_shear, g_vol.norm_hotspot);
+        const double rho = fmax(dv2_rho(rc, zeta, P) * F, 0.0);
+        const double t = fmin(fmax(dv2_T(rc, zeta, P) * F / g_vol.t_peak, 0.0), 1.0);
+        const double alpha_eff = g_vol.absorption * rho * (1.0 + g_vol.grazing_gain * (1.0 - mu));
+        const float op = (float)(1.0 - exp(-alpha_eff * ds));
+        if (!(op > 0.0f)) continue;
+        v3 col = apply_g_factor(dv2_color((float)t), v3_make((float)sx, (float)sy, (float)sz), (float)rc, to_cam, cam_pos,
+                                r_inner, r_outer, tilt_rad);
+        const float front = 1.0f - *alpha_total;
+        accum->x += col.x * op * front;
+        accum->y += col.y * op * front;
+        accum->z += col.z * op * front;
+        *alpha_total = 1.0f - front * (1.0f - op);
+    }
+}
+
 /* ---- camera uniforms as uploaded at render.py:3886-3892 ----------------- */
 typedef struct {
     f32 cam_pos[3], cam_right[3], cam_up[3], cam_forward[3];
@@ -586,7 +791,9 @@ ORACLE_API int64_t oracle_ray_march(const oracle_camera *cam, const oracle_march
                 float new_z = new_pos.z, new_y = new_pos.y;
                 float f_old = old_z - old_y * tan_t;
                 float f_new = new_z - new_y * tan_t;
-                if (f_old * f_new < 0) {
+                if (g_vol.on) {
+                    volume_segment(old_pos, new_pos, dir_, tilt_rad, t_offset, cp, r_inner, r_outer, &accum_disk, &disk_alpha_total);
+                } else if (f_old * f_new < 0) {
                     float t_frac = f_old / (f_old - f_new + 1e-8f);
                     float hit_x = old_pos.x + t_frac * (new_pos.x - old_pos.x);
                     float hit_y = old_pos.y + t_frac * (new_pos.y - old_pos.y);

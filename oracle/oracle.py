@@ -74,6 +74,11 @@ def load(fast=False) -> C.CDLL:
     lib.oracle_generate_background.argtypes = [F, I32, I32, I32, C.c_float, C.c_float, C.c_float, C.c_float]
     lib.oracle_eval_noise.restype = None
     lib.oracle_eval_noise.argtypes = [F, I64, I32, I32, C.c_float, C.c_float, F]
+    D = C.POINTER(C.c_double)
+    lib.oracle_dv2_eval.restype = None
+    lib.oracle_dv2_eval.argtypes = [C.c_void_p, I32, D, D, D, I64, C.c_double, C.c_double, D]
+    lib.oracle_set_volume.restype = None
+    lib.oracle_set_volume.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I32]
     lib.oracle_num_threads.restype = I32
     lib.oracle_set_num_threads.argtypes = [I32]
     _libs[name] = lib
@@ -145,8 +150,29 @@ def compose_disk_texture(comp, omega_rows, edge, stats, row_stats, t_offset: flo
     return tex
 
 
+def dv2_eval(cparams, field: int, r, z=None, phi=None, norm_shear: float = 0.0, norm_hotspot: float = 0.0, fast=False):
+    """Disk V2 field ``field`` (ids of include/bhr_disk_v2.h) at broadcast points; 11 / 12 return the raw
+    shear / hotspot sums.  ``cparams``: a ctypes struct with the layout of bhr_disk_v2_params."""
+    arrs = np.broadcast_arrays(*[np.asarray(a, dtype=np.float64) for a in (r, z, phi) if a is not None])
+    shape = arrs[0].shape
+    it = iter(arrs)
+    get = lambda a: np.ascontiguousarray(next(it)).ravel() if a is not None else None
+    rr, zz, pp = get(r), get(z), get(phi)
+    out = np.empty(rr.size, dtype=np.float64)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+    load(fast).oracle_dv2_eval(C.byref(cparams), field, dp(rr), dp(zz), dp(pp), rr.size, norm_shear, norm_hotspot, dp(out))
+    return out.reshape(shape)
+
+
 class OracleRenderer:
     """CPU twin of TaichiRenderer's render path (render.py:2199-2266, 3865-3923)."""
+
+    def set_volume(self, cparams=None, norm_shear=1.0, norm_hotspot=1.0, t_peak=1.0, absorption=4.0, grazing_gain=1.0,
+                   substeps=2):
+        """Finite-thickness Disk V2 source for the following march() calls of THIS build of the library
+        (None: back to the textured thin disk).  Mirrors bhr_set_disk_source(BHR_DISK_V2_VOLUME)."""
+        self.lib.oracle_set_volume(C.byref(cparams) if cparams is not None else None, norm_shear, norm_hotspot, t_peak,
+                                   absorption, grazing_gain, substeps)
 
     def __init__(self, width, height, skybox, disk_tex, step_size=0.1, r_max=10.0, r_disk_inner=2.0,
                  r_disk_outer=15.0, disk_tilt=0.0, anti_alias="disabled", aa_strength=1.0,

@@ -192,3 +192,45 @@ def test_differentials_do_not_change_aa_off_pixels(oracle):
     a = R.render([6, 0, 0.5], 90, skip_differentials=False)
     b = R.render([6, 0, 0.5], 90, skip_differentials=True)
     np.testing.assert_array_equal(a, b)
+
+
+# ---- Disk V2 restatement in the oracle, pinned by the reference package's own tables ----------------
+def test_oracle_disk_v2_fields_match_reference_tables(oracle):
+    import bhr_amd  # noqa: F401
+    from bhr_amd import disk_v2 as dv
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "disk_v2.npz"))
+    P = dv.DiskV2Params()
+    cp = dv.pack_params(P)
+    tol = dict(rtol=2e-14, atol=1e-15)
+    r, zf = gold["r"], gold["zf"]
+    rr = np.repeat(r[:, None], len(zf), axis=1)
+    zz = zf[None, :] * gold["H"][:, None]
+    ev = lambda f, *a, **k: oracle.dv2_eval(cp, f, *a, **k)
+    np.testing.assert_allclose(ev(dv.F_H, r), gold["H"], **tol)
+    np.testing.assert_array_equal(ev(dv.F_MASK_R, r) > 0.5, gold["mask_r"])
+    np.testing.assert_allclose(ev(dv.F_W_R, r), gold["W_r"], **tol)
+    np.testing.assert_allclose(ev(dv.F_W_Z, rr, zz), gold["W_z"], **tol)
+    np.testing.assert_array_equal(ev(dv.F_MASK_VOL, rr, zz) > 0.5, gold["mask_vol"])
+    np.testing.assert_allclose(ev(dv.F_OMEGA, r), gold["omega"], **tol)
+    np.testing.assert_allclose(ev(dv.F_RHO_MID, r), gold["rho_mid"], **tol)
+    np.testing.assert_allclose(ev(dv.F_T_MID, r), gold["T_mid"], **tol)
+    np.testing.assert_allclose(ev(dv.F_RHO, rr, zz), gold["rho"], **tol)
+    np.testing.assert_allclose(ev(dv.F_T, rr, zz), gold["T"], **tol)
+    rg, pg = np.meshgrid(gold["rg"], gold["phig"], indexing="ij")
+    np.testing.assert_allclose(ev(dv.F_MODE, rg, None, pg), gold["F_mode"], rtol=1e-13, atol=1e-14)
+    for seed in (7, 42, 123):
+        # the reference normalises each signed sum by its maximum over the evaluated array
+        cs = dv.pack_params(P, None, shear_seed=seed, hotspot_seed=seed)
+        sp = dv.DiskV2StructureParams()
+        raw_s = oracle.dv2_eval(cs, dv.F_SHEAR, rg, None, pg)
+        raw_h = oracle.dv2_eval(cs, dv.F_HOTSPOT, rg, None, pg)
+        wr = oracle.dv2_eval(cs, dv.F_W_R, rg) > 0
+        f_s = np.where(wr, 1.0 + sp.shear_strength * raw_s / np.abs(raw_s).max(), 1.0)
+        f_h = np.where(wr, 1.0 + sp.hotspot_strength * raw_h / np.abs(raw_h).max(), 1.0)
+        np.testing.assert_allclose(f_s, gold[f"F_shear_{seed}"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(f_h, gold[f"F_hotspot_{seed}"], rtol=1e-12, atol=1e-13)
+        ct = dv.pack_params(P, None, shear_seed=seed, hotspot_seed=seed + 1)      # structure_modulation: seed, seed + 1
+        m_s = np.abs(oracle.dv2_eval(ct, dv.F_SHEAR, rg, None, pg)).max()
+        m_h = np.abs(oracle.dv2_eval(ct, dv.F_HOTSPOT, rg, None, pg)).max()
+        np.testing.assert_allclose(oracle.dv2_eval(ct, dv.F_TOTAL, rg, None, pg, norm_shear=m_s, norm_hotspot=m_h),
+                                   gold[f"F_total_{seed}"], rtol=1e-12, atol=1e-13)
