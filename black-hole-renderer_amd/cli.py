@@ -3,7 +3,7 @@
 Additions: ``--device hip`` (the default and only backend; ``gpu`` is accepted as an alias, ``cpu`` is
 refused -- this build has no CPU path), ``-r 8k``, ``--gpus N`` (row-block tiling of a still image
 inside one process; for ``--video`` launch one process per GPU with torchrun and frames are sharded
-round-robin by RANK / WORLD_SIZE).
+round-robin by RANK / WORLD_SIZE), ``--disk_model`` (the analytic Disk V2 sources of the march kernel).
 """
 from __future__ import annotations
 
@@ -47,6 +47,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--aa_strength", type=float, default=1.0, help="LOD multiplier 0.5-2.0 (default: 1.0)")
     p.add_argument("--device", "-d", type=str, default="hip", choices=["hip", "gpu", "cpu"],
                    help="hip (MI355X). 'gpu' is an alias; 'cpu' is refused: there is no CPU path")
+    p.add_argument("--disk_model", type=str, default="texture", choices=["texture", "v2", "v2_volume"],
+                   help="disk source of still images: the lifecycle texture (default), the analytic Disk V2 model at "
+                        "each plane crossing, or its finite-thickness emission-absorption integral")
     p.add_argument("--gpus", type=int, default=1, help="row-block tile a still image over N GPUs of this node")
     p.add_argument("--ignore_taichi_cache", action="store_true", help="accepted for compatibility; no effect")
     p.add_argument("--video", action="store_true", help="render frames and assemble a video")
@@ -82,6 +85,8 @@ def validate_args(args) -> None:
         raise ValueError(f"orbit_degrees must be finite, got {args.orbit_degrees}")
     if args.disk_texture and (args.video or args.interactive):
         raise ValueError("--disk_texture only supports still images; video/interactive use the lifecycle system")
+    if getattr(args, "disk_model", "texture") != "texture" and (args.video or args.disk_texture):
+        raise ValueError("--disk_model v2/v2_volume renders still images and takes no --disk_texture")
     if getattr(args, "device", "hip") == "cpu":
         raise ValueError("--device cpu: this build renders on the MI355X only (no CPU path)")
     if getattr(args, "gpus", 1) < 1:
@@ -131,6 +136,6 @@ def main(argv=None) -> int:
         disk_texture_path=args.disk_texture, r_disk_inner=args.disk_inner_radius,
         r_disk_outer=args.disk_outer_radius, disk_tilt=args.disk_tilt, lens_flare=args.lens_flare,
         anti_alias=args.anti_alias, aa_strength=args.aa_strength, disk_rotation_speed=args.disk_rotation_speed,
-        gpus=args.gpus)
+        gpus=args.gpus, disk_model=args.disk_model)
     drivers.save_image(img, args.output)
     return 0

@@ -67,6 +67,18 @@ def advance_lifecycle_frame(renderer: HipRenderer, factories: dict, t: float, dt
         renderer.compose_interactive_texture(solo_idx=solo_idx)
 
 
+def use_analytic_disk(renderer: HipRenderer, disk_model: str) -> bool:
+    """--disk_model v2 / v2_volume: Disk V2 with the renderer's radii and default structure (seed 42)."""
+    if disk_model == "texture":
+        return False
+    if disk_model not in ("v2", "v2_volume"):
+        raise ValueError(f"unknown disk_model {disk_model!r}")
+    from .disk_v2 import DiskV2Params
+    renderer.use_disk_v2(DiskV2Params(r_in=renderer.r_disk_inner, r_out=renderer.r_disk_outer), seed=42,
+                         volume=disk_model == "v2_volume")
+    return True
+
+
 def make_renderer(width, height, cam_pos, fov, step_size=0.1, skybox_path=None, n_stars=6000, tex_w=2048,
                   tex_h=1024, r_max=10.0, disk_texture_path=None, r_disk_inner=R_DISK_INNER_DEFAULT,
                   r_disk_outer=R_DISK_OUTER_DEFAULT, disk_tilt=0.0, lens_flare=False, anti_alias="disabled",
@@ -95,7 +107,7 @@ def render_image(width: int, height: int, cam_pos: List[float], fov: float, step
                  disk_tilt: float = 0.0, lens_flare: bool = False, anti_alias: str = "disabled",
                  aa_strength: float = 1.0, disk_rotation_speed: float = 0.1, disk_generation_scale: int = 2,
                  force_regenerate_disk_texture: bool = False, ignore_taichi_cache: bool = False,
-                 gpus: int = 1) -> np.ndarray:
+                 gpus: int = 1, disk_model: str = "texture") -> np.ndarray:
     """One frame -> (H, W, 3) float32 (render.py:4031-4076).  ``gpus > 1`` tiles the frame in row
     blocks over that many devices of this node (bhr_group_render)."""
     if gpus > 1:
@@ -105,11 +117,13 @@ def render_image(width: int, height: int, cam_pos: List[float], fov: float, step
                                   disk_texture_path=disk_texture_path, r_disk_inner=r_disk_inner,
                                   r_disk_outer=r_disk_outer, disk_tilt=disk_tilt, lens_flare=lens_flare,
                                   anti_alias=anti_alias, aa_strength=aa_strength,
-                                  disk_rotation_speed=disk_rotation_speed)
+                                  disk_rotation_speed=disk_rotation_speed, disk_model=disk_model)
     renderer, use_lifecycle, n_r, n_phi = make_renderer(
         width, height, cam_pos, fov, step_size, skybox_path, n_stars, tex_w, tex_h, r_max, disk_texture_path,
         r_disk_inner, r_disk_outer, disk_tilt, lens_flare, anti_alias, aa_strength, disk_rotation_speed)
-    if use_lifecycle:
+    if use_analytic_disk(renderer, disk_model):
+        pass
+    elif use_lifecycle:
         factories = init_lifecycle_system(renderer, n_r, n_phi, seed=42)
         advance_lifecycle_frame(renderer, factories, t=0.0, dt=0.0, recompute_stats=True)
     t0 = time.time()

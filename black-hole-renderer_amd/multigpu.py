@@ -7,6 +7,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -51,13 +52,20 @@ def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_diff
 def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devices=None, **kw) -> np.ndarray:
     """render_image over ``gpus`` row blocks.  ``devices`` maps block k to a HIP device ordinal
     (default k); every device builds the same deterministic scene."""
-    from .drivers import make_renderer, init_lifecycle_system, advance_lifecycle_frame
+    from .drivers import make_renderer, init_lifecycle_system, advance_lifecycle_frame, use_analytic_disk
+    disk_model = kw.pop("disk_model", "texture")
+    if devices is None and os.environ.get("BHR_TILE_DEVICES"):     # e.g. "0,0": rehearse two tiles on one card
+        devices = [int(d) for d in os.environ["BHR_TILE_DEVICES"].split(",")]
     devices = list(range(gpus)) if devices is None else list(devices)
+    if len(devices) != gpus:
+        raise ValueError(f"{gpus} row blocks need {gpus} device ordinals, got {devices}")
     tiles = []
     for k, rows in enumerate(row_blocks(height, gpus)):
         r, use_lifecycle, n_r, n_phi = make_renderer(width, height, cam_pos, fov, device_index=devices[k],
                                                      rows=rows, lens_flare=False, **kw)
-        if use_lifecycle:
+        if use_analytic_disk(r, disk_model):
+            pass
+        elif use_lifecycle:
             factories = init_lifecycle_system(r, n_r, n_phi, seed=42)
             advance_lifecycle_frame(r, factories, t=0.0, dt=0.0, recompute_stats=True)
         tiles.append(r)

@@ -146,6 +146,34 @@ def test_video_frames_resume_and_sharding(tmp_path):
         np.testing.assert_array_equal(np.array(Image.open(os.path.join(d2, f"frame_{k:04d}.png"))), frames1[k])
 
 
+def test_disk_model_flag():
+    from bhr_amd import cli
+    assert cli.parse_args([]).disk_model == "texture"
+    a = cli.parse_args(["--disk_model", "v2_volume"])
+    cli.validate_args(a)
+    for bad in (["--disk_model", "v2", "--video"], ["--disk_model", "v2_volume", "--disk_texture", "x.png"]):
+        with pytest.raises(ValueError):
+            cli.validate_args(cli.parse_args(bad))
+
+
+@pytest.mark.gpu
+def test_cli_disk_models(tmp_path):
+    """Still images with the analytic Disk V2 sources, single context and two row blocks."""
+    from PIL import Image
+    imgs = {}
+    for model, gpus in (("v2", 1), ("v2_volume", 1), ("v2_volume", 2)):
+        out = tmp_path / f"{model}_{gpus}.png"
+        env = dict(os.environ, BHR_TILE_DEVICES="0,0")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "render.py"), "-r", "sd", "--n_stars", "200", "-o", str(out),
+                            "--pov", "9", "0", "1.2", "--ar1", "2", "--ar2", "10", "--disk_model", model, "--gpus", str(gpus)],
+                           capture_output=True, text=True, cwd=ROOT, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        imgs[(model, gpus)] = np.array(Image.open(out)).astype(np.int32)
+    assert imgs[("v2", 1)].max() > 100 and imgs[("v2_volume", 1)].max() > 100
+    assert np.abs(imgs[("v2", 1)] - imgs[("v2_volume", 1)]).mean() > 1.0              # different disks
+    assert np.abs(imgs[("v2_volume", 1)] - imgs[("v2_volume", 2)]).max() <= 1          # tiles == whole frame (8-bit)
+
+
 @pytest.mark.gpu
 def test_cli_end_to_end(tmp_path):
     out = tmp_path / "cli.png"
