@@ -36,7 +36,7 @@ WORKLOADS = {
     "sd": dict(width=640, height=360, cam_pos=[6.0, 0.0, 0.5], fov=90.0, step_size=0.1, anti_alias="disabled",
                disk_tilt=0.0),
     "4k": dict(width=3840, height=2160, cam_pos=[6.0, 0.0, 0.5], fov=90.0, step_size=0.1, anti_alias="lod_radius",
-               disk_tilt=25.0),
+               disk_tilt=25.0, lens_flare=True),
     "8k": dict(width=7680, height=4320, cam_pos=[6.0, 0.0, 0.5], fov=90.0, step_size=0.05, anti_alias="disabled",
                disk_tilt=0.0),
 }
@@ -114,13 +114,14 @@ def main():
 
     # frames sharded round-robin over ranks (configs[4]); the camera is the static default pov
     compaction = args.persistent
+    flare = bool(wl.get("lens_flare", False))       # configs[2]: on the device, inside the timed step
     for _ in range(args.warmup):
-        renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction)
+        renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
     renderer.timing_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction)
+        renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -166,13 +167,14 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} {wl['width']}x{wl['height']} default scene, pov 6 0 0.5, "
-                                   f"fov {wl['fov']:g}, step_size {wl['step_size']}, anti_alias {wl['anti_alias']}",
+                                   f"fov {wl['fov']:g}, step_size {wl['step_size']}, anti_alias {wl['anti_alias']}, "
+                                   f"disk_tilt {wl['disk_tilt']:g}, lens_flare {'on' if flare else 'off'}",
                        "scene": scene_note, "frames_per_rank": args.steps,
                        "sharding": "independent frames per rank, no collective",
                        "march_schedule": "persistent+refill" if args.persistent else "tile",
                        "march_math": renderer.math,
                        "ray_steps_per_frame": int(steps_per_frame), "steps_per_ray": steps_per_frame / pixels},
-            "kernel_ms": {"march": march_ms, "bloom_and_combine": bloom_ms, "frames_timed": n_frames,
+            "kernel_ms": {"march": march_ms, "bloom_combine_flare" if flare else "bloom_and_combine": bloom_ms, "frames_timed": n_frames,
                           "march_vgprs": c["march_vgprs"]},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,

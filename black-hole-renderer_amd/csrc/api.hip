@@ -442,6 +442,15 @@ int32_t bhr_write_layer(bhr_ctx *ctx, int32_t layer, const float *in) {
     return upload(ctx, dst, in, (size_t)ctx->rows * ctx->cfg.width * 3 * sizeof(float));
 }
 
+int32_t bhr_bloom(bhr_ctx *ctx) {
+    if (!ctx) return bhr_fail(BHR_ERR_INVALID, "bhr_bloom: null ctx");
+    if (ctx->rows != ctx->cfg.height)
+        return bhr_fail(BHR_ERR_INVALID, "bhr_bloom: needs a whole-frame context (rows %d of %d)", ctx->rows, ctx->cfg.height);
+    BHR_TRY(use_device(ctx));
+    BHR_TRY(bhr_launch_bloom_h(ctx));
+    return bhr_launch_bloom_v(ctx, 1);
+}
+
 int32_t bhr_lens_flare(bhr_ctx *ctx) {
     if (!ctx) return bhr_fail(BHR_ERR_INVALID, "bhr_lens_flare: null ctx");
     if (ctx->rows != ctx->cfg.height)

@@ -26,7 +26,8 @@ namespace {
 constexpr int WPAD = 8;       // zero entries behind w[R] in the weight table (window overhang <= 6)
 constexpr int HB_PIX = 1024;  // pixels per H-pass block (256 threads x 4)
 constexpr int VB_COLS = 32;   // columns per V-pass block
-constexpr int VB_ROWS = 128;  // output rows per V-pass block (8 row-lanes x 4 groups x 4 rows)
+// output rows per V-pass block = 8 row-lanes x G groups x 4 rows: G = 4 (128 rows) for short kernels, G = 8
+// (256 rows) when the 2R halo rows would otherwise outweigh the tile (R >= 128: 8k frames)
 
 __global__ void bloom_weights_kernel(float *wtab, int R, float sigma_scale) {
     int d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(256) void bloom_h_kernel(const float *__restrict__ 
     }
 }
 
-// grid (ceil(W / 32), ceil(rows / 128)).  Thread = (column, row-lane); 4 groups of 4 rows each.
+// grid (ceil(W / 32), ceil(rows / (32 G))).  Thread = (column, row-lane); G groups of 4 rows each.
+template <int G>
 __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ hblur, const float *__restrict__ bg,
                                                       const float *__restrict__ disk, float *__restrict__ blur_out,
                                                       float *__restrict__ final_out, const float *__restrict__ wext,
@@ -139,14 +141,15 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
     const int col = threadIdx.x & (VB_COLS - 1);
     const int lane_g = threadIdx.x >> 5;           // 0..7
     const int x = blockIdx.x * VB_COLS + col;
+    constexpr int VB_ROWS = 32 * G;
     const int y0 = blockIdx.y * VB_ROWS;           // local row of the first output of the tile
     const int xstride = 2 * R4 + 8;
     const int tile_rows = VB_ROWS + 2 * R4 + 4;
     const int M = (2 * R4) / 4 + 1;
 
-    float res[4][4][3];
+    float res[G][4][3];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int k = 0; k < 4; ++k) res[g][k][0] = res[g][k][1] = res[g][k][2] = 0.0f;
 
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             __syncthreads();
-            // stage rows [y0 - R4, y0 + 128 + R4 + 4) x 32 columns of plane c, transposed
+            // stage rows [y0 - R4, y0 + VB_ROWS + R4 + 4) x 32 columns of plane c, transposed
             for (int k = threadIdx.x; k < tile_rows * VB_COLS; k += 256) {
                 int r = k >> 5, cc = k & (VB_COLS - 1);
                 int yl = y0 - R4 + r;              // local row
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
             }
             __syncthreads();
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < G; ++g) {
                 const int grp = lane_g + 8 * g;    // group of 4 rows inside the tile
                 float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 conv4(lds + col * S + 4 * grp, M, wext + c * xstride, acc);
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
     }
     if (x >= W) return;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < G; ++g) {
         const int grp = lane_g + 8 * g;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -205,9 +208,11 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
     }
 }
 
-int v_stride(int R) {   // LDS column stride: >= tile rows, multiple of 4 with an odd quotient (bank spread)
+// measured: 256-row tiles win at 8k (R = 153: 2.0 -> 1.74 ms) and lose at 4k (R = 76: one block fewer per CU)
+int v_groups(int R, int rows) { return (R >= 128 && rows > 128) ? 8 : 4; }
+int v_stride(int R, int groups) {   // LDS column stride: >= tile rows, multiple of 4 with an odd quotient (bank spread)
     const int R4 = (R + 3) & ~3;
-    int s = VB_ROWS + 2 * R4 + 4;
+    int s = 32 * groups + 2 * R4 + 4;
     if (((s >> 2) & 1) == 0) s += 4;
     return s;
 }
@@ -229,9 +234,11 @@ int32_t bhr_bloom_prepare(bhr_ctx *ctx) {
     hipLaunchKernelGGL(bloom_wsum_kernel, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wtab, ctx->d_wsum_h, R, W);
     hipLaunchKernelGGL(bloom_wsum_kernel, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wtab, ctx->d_wsum_v, R, H);
     BHR_HIP(hipGetLastError());
-    const size_t v_lds = (size_t)VB_COLS * v_stride(R) * sizeof(float);
+    const int G = v_groups(R, ctx->rows);
+    const size_t v_lds = (size_t)VB_COLS * v_stride(R, G) * sizeof(float);
     if (v_lds > 48 * 1024)
-        BHR_HIP(hipFuncSetAttribute((const void *)bloom_v_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v_lds));
+        BHR_HIP(hipFuncSetAttribute(G == 8 ? (const void *)bloom_v_kernel<8> : (const void *)bloom_v_kernel<4>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)v_lds));
     ctx->bloom_ready = 1;
     return BHR_OK;
 }
@@ -253,12 +260,15 @@ int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom) {
     const int W = ctx->cfg.width, H = ctx->cfg.height, R = ctx->bloom_R;
     int32_t rc = bhr_bloom_prepare(ctx);
     if (rc) return rc;
-    const int S = v_stride(R);
-    dim3 grid((W + VB_COLS - 1) / VB_COLS, (ctx->rows + VB_ROWS - 1) / VB_ROWS), block(256);
+    const int G = v_groups(R, ctx->rows), S = v_stride(R, G), vb_rows = 32 * G;
+    dim3 grid((W + VB_COLS - 1) / VB_COLS, (ctx->rows + vb_rows - 1) / vb_rows), block(256);
     size_t lds = with_bloom ? (size_t)VB_COLS * S * sizeof(float) : 0;
-    hipLaunchKernelGGL(bloom_v_kernel, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk,
-                       ctx->d_blur, ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S,
-                       with_bloom);
+    if (G == 8)
+        hipLaunchKernelGGL(bloom_v_kernel<8>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
+                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom);
+    else
+        hipLaunchKernelGGL(bloom_v_kernel<4>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
+                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom);
     BHR_HIP(hipGetLastError());
     return BHR_OK;
 }

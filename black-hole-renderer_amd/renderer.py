@@ -346,6 +346,11 @@ class HipRenderer:
             raise ValueError(f"layer must be {(self.rows, self.width, 3)}, got {data.shape}")
         _lib.check(self._lib.bhr_write_layer(self._ctx, layer, _lib.fptr(data)))
 
+    def bloom_only(self) -> None:
+        """BLUR <- bloom(DISK), FINAL <- clip(BG + DISK + BLUR, 0, 1) on the layers in the context
+        (_bloom_kernel + combine, render.py:3914-3918)."""
+        _lib.check(self._lib.bhr_bloom(self._ctx))
+
     def apply_lens_flare(self) -> None:
         """FINAL <- clip(FINAL + flare(DISK), 0, 1) on the device (_apply_lens_flare, render.py:3925-4028)."""
         _lib.check(self._lib.bhr_lens_flare(self._ctx))

@@ -181,6 +181,11 @@ BHR_API int32_t bhr_read_layer(bhr_ctx *ctx, int32_t layer, float *out);
 /* field.from_numpy() for a frame layer: replaces the context's rows of FINAL, BG, DISK or BLUR with
  * caller data, e.g. to post-process a frame composed elsewhere.  Synchronises. */
 BHR_API int32_t bhr_write_layer(bhr_ctx *ctx, int32_t layer, const float *in);
+/* self._bloom_kernel(disk_layer_field, bright_field, blur_field, 0, 0.4, int(0.02 W), (W / 640)^2) followed by
+ * clip(img + disk + blur, 0, 1) (render.py:3914-3918), standalone on the layers currently in the context:
+ * BLUR <- bloom(DISK), FINAL <- clip(BG + DISK + BLUR, 0, 1).  Whole-frame context (row blocks need their
+ * neighbours' halo rows: bhr_group_render).  Asynchronous. */
+BHR_API int32_t bhr_bloom(bhr_ctx *ctx);
 /* TaichiRenderer._apply_lens_flare(final, disk) (render.py:3925-4028) on the device, standalone:
  * FINAL <- clip(FINAL + flare(DISK), 0, 1) for a whole-frame context.  bhr_render / bhr_group_render
  * with BHR_LENS_FLARE run the same kernels after the combine.  Asynchronous. */

@@ -133,6 +133,29 @@ def test_bloom_isolated(oracle, hip_lib):
     hip.close()
 
 
+def test_bloom_wide_frame_tall_tiles(oracle, hip_lib):
+    """R = int(0.02 W) >= 128 selects the 256-row V-pass tiles (8k frames): a 6500-pixel-wide strip with a
+    synthetic disk layer through the standalone layer API, against the oracle's bloom."""
+    from bhr_amd import HipRenderer, _lib
+    w, h = 6500, 300                                   # R = 130, ragged in both directions
+    rng = np.random.default_rng(11)
+    disk = np.zeros((h, w, 3), np.float32)
+    ys, xs = rng.integers(0, h, 4000), rng.integers(0, w, 4000)
+    disk[ys, xs] = rng.random((4000, 3), dtype=np.float32)
+    disk[100:140, 3000:3600] = 0.7
+    hip = HipRenderer(w, h, np.zeros((16, 32, 3), np.float32), np.zeros((32, 64, 4), np.float32))
+    hip.write_layer(_lib.LAYER_DISK, disk)
+    hip.write_layer(_lib.LAYER_BG, np.zeros_like(disk))
+    hip.bloom_only()
+    blur = hip.read_layer(_lib.LAYER_BLUR)
+    ora = oracle.OracleRenderer(w, h, np.zeros((16, 32, 3), np.float32), np.zeros((32, 64, 4), np.float32), fast=True)
+    rblur, _ = ora.bloom(np.ascontiguousarray(disk.transpose(1, 0, 2)))
+    np.testing.assert_allclose(blur, rblur.transpose(1, 0, 2), atol=3e-6, rtol=2e-5)
+    final = hip.read_layer(_lib.LAYER_FINAL)
+    np.testing.assert_allclose(final, np.clip(disk + blur, 0, 1), atol=1e-6)
+    hip.close()
+
+
 def test_u8_quantisation(hip_lib):
     sky, tex = scenes.analytic_skybox(), scenes.analytic_disk()
     from bhr_amd import HipRenderer

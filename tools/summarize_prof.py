@@ -15,13 +15,11 @@ def find(sub, suffix):
 
 
 def short(name):
-    for k in ("march_tile_kernel", "march_persistent_kernel", "bloom_h_kernel", "bloom_v_kernel", "background_kernel",
-              "compose_kernel", "mip_down_kernel", "quantize_u8_kernel", "bloom_wext", "bloom_wsum", "bloom_weights",
-              "entity_kernel", "stats_fields_kernel", "select_hist_kernel", "row_stats_kernel", "disk_v2"):
-        if k in name:
-            tpl = "<diff>" if "ILb1E" in name or "<true>" in name else ""
-            return k + tpl
-    return name.split("(")[0][-60:]
+    """'void (anonymous namespace)::march_tile_kernel<true, 0>(BhrMarchArgs)' -> 'march_tile_kernel<true, 0>'"""
+    import re
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "").strip()
+    m = re.match(r"([A-Za-z_][A-Za-z0-9_:]*)(<[^(]*>)?", n)
+    return (m.group(1) + (m.group(2) or "")) if m else n[:60]
 
 
 print(f"# rocprofv3 summary: {os.path.basename(out)}\n")
