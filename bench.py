@@ -86,6 +86,11 @@ def cpu_baseline(wl, sky, tex):
 
 def main():
     args = parse()
+    # Only the JSON line may reach stdout: RCCL prints a version banner there when NCCL_DEBUG is set, the scene
+    # set-up prints progress.  Everything written to fd 1 before the result goes to stderr instead.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -99,7 +104,8 @@ def main():
     backend = os.environ.get("BHR_DIST_BACKEND", "nccl")
     if "BHR_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["BHR_FORCE_DEVICE"])
-    dist = D.init(backend, local_rank) if world > 1 else None
+    # BHR_DIST_FORCE=1: initialise the process group even for one rank (rehearses RCCL init + all-reduce)
+    dist = D.init(backend, local_rank) if (world > 1 or os.environ.get("BHR_DIST_FORCE") == "1") else None
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from bhr_amd import workloads
@@ -190,7 +196,8 @@ def main():
                              "note": "informational A/B in the same process; `value` above is the default (parity-certified) arithmetic"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, sky, tex)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
