@@ -536,6 +536,24 @@ int32_t bhr_timing_reset(bhr_ctx *ctx) {
     return BHR_OK;
 }
 
+// Direct xGMI copies between the tiles' devices: without peer access hipMemcpyPeerAsync stages through
+// host memory.  Tried once per ordered device pair; a refusal is not an error (the staged copy still works).
+static void enable_peer_access(bhr_ctx **ctxs, int32_t n) {
+    static bool tried[64][64];
+    for (int k = 0; k < n; ++k)
+        for (int q = 0; q < n; ++q) {
+            const int a = ctxs[k]->cfg.device, b = ctxs[q]->cfg.device;
+            if (a == b || a < 0 || b < 0 || a >= 64 || b >= 64 || tried[a][b]) continue;
+            tried[a][b] = true;
+            int can = 0;
+            if (hipSetDevice(a) != hipSuccess || hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
+                (void)hipGetLastError();
+                continue;
+            }
+            if (hipDeviceEnablePeerAccess(b, 0) != hipSuccess) (void)hipGetLastError();   // e.g. already enabled
+        }
+}
+
 int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host) {
     if (!ctxs || n <= 0 || !cam) return bhr_fail(BHR_ERR_INVALID, "bhr_group_render: bad argument");
     const int W = ctxs[0]->cfg.width, H = ctxs[0]->cfg.height;
@@ -547,6 +565,7 @@ int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint3
         expect = ctxs[k]->cfg.row1;
     }
     if (expect != H) return bhr_fail(BHR_ERR_INVALID, "bhr_group_render: tiles cover %d of %d rows", expect, H);
+    enable_peer_access(ctxs, n);
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     const size_t R = ctxs[0]->bloom_R;
 
@@ -622,17 +641,21 @@ int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint3
             BHR_HIP(hipEventRecord(ctxs[k]->ev[2], ctxs[k]->stream));
         }
     }
-    // phase 4: gather the final tiles
+    // phase 4: gather the final tiles -- every device copies into its own pinned buffer concurrently, the host
+    // then assembles the frame (a pageable destination would serialise the eight DMA streams)
     if (out_host) {
         for (int k = 0; k < n; ++k) {
             BHR_TRY(use_device(ctxs[k]));
-            BHR_HIP(hipMemcpyAsync(out_host + (size_t)ctxs[k]->cfg.row0 * W * 3, ctxs[k]->d_final,
-                                   (size_t)ctxs[k]->rows * W * 3 * sizeof(float), hipMemcpyDeviceToHost, ctxs[k]->stream));
+            const size_t bytes = (size_t)ctxs[k]->rows * W * 3 * sizeof(float);
+            BHR_TRY(ensure_pinned(ctxs[k], bytes));
+            BHR_HIP(hipMemcpyAsync(ctxs[k]->h_pinned, ctxs[k]->d_final, bytes, hipMemcpyDeviceToHost, ctxs[k]->stream));
         }
     }
     for (int k = 0; k < n; ++k) {
         BHR_TRY(use_device(ctxs[k]));
         BHR_HIP(hipStreamSynchronize(ctxs[k]->stream));
+        if (out_host)
+            memcpy(out_host + (size_t)ctxs[k]->cfg.row0 * W * 3, ctxs[k]->h_pinned, (size_t)ctxs[k]->rows * W * 3 * sizeof(float));
     }
     return BHR_OK;
 }
