@@ -133,16 +133,17 @@ def test_bloom_isolated(oracle, hip_lib):
     hip.close()
 
 
-def test_bloom_wide_frame_tall_tiles(oracle, hip_lib):
-    """R = int(0.02 W) >= 128 selects the 256-row V-pass tiles (8k frames): a 6500-pixel-wide strip with a
-    synthetic disk layer through the standalone layer API, against the oracle's bloom."""
+@pytest.mark.parametrize("w,h", [(6500, 300), (3300, 200)])
+def test_bloom_wide_frame_tall_tiles(w, h, oracle, hip_lib):
+    """The V pass picks its tile height from R = int(0.02 W): 64 rows below R = 64 (every other test), 128 rows
+    up to R = 127 (w = 3300), 256 rows above (w = 6500, the 8k case).  Wide strips with a synthetic disk layer
+    through the standalone layer API, against the oracle's bloom; ragged in both directions."""
     from bhr_amd import HipRenderer, _lib
-    w, h = 6500, 300                                   # R = 130, ragged in both directions
     rng = np.random.default_rng(11)
     disk = np.zeros((h, w, 3), np.float32)
     ys, xs = rng.integers(0, h, 4000), rng.integers(0, w, 4000)
     disk[ys, xs] = rng.random((4000, 3), dtype=np.float32)
-    disk[100:140, 3000:3600] = 0.7
+    disk[100:140, 1500:2100] = 0.7
     hip = HipRenderer(w, h, np.zeros((16, 32, 3), np.float32), np.zeros((32, 64, 4), np.float32))
     hip.write_layer(_lib.LAYER_DISK, disk)
     hip.write_layer(_lib.LAYER_BG, np.zeros_like(disk))
