@@ -99,3 +99,66 @@ def test_device_and_host_lifecycle_render_the_same_frame(hip_lib):
         imgs.append(r.render([6, 0, 0.5], 60))
         r.close()
     assert np.abs(imgs[0] - imgs[1]).max() < 2e-5
+
+
+# ---- the reference's test_lifecycle_perf.py restated: same 640x360 set-up, same budgets, same smoke asserts ----
+@pytest.fixture(scope="module")
+def sd_setup(hip_lib):
+    from bhr_amd import drivers
+    cam, fov = [6, 0, 0.5], 90
+    r, use_lifecycle, n_r, n_phi = drivers.make_renderer(640, 360, cam, fov, n_stars=200, tex_w=256, tex_h=128)
+    assert use_lifecycle
+    fac = drivers.init_lifecycle_system(r, n_r, n_phi, seed=42)
+    yield r, fac, cam, fov
+    r.close()
+
+
+def _median_ms(renderer, fn, n=5):
+    import time
+    fn()
+    renderer.sync()
+    times = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        renderer.sync()
+        times.append(time.perf_counter() - t0)
+    return float(np.median(times)) * 1e3
+
+
+def test_reference_time_budgets(sd_setup):
+    """test_lifecycle_perf.py:93-135: background < 500 ms, entity accumulation < 200 ms, compose + mipmaps
+    < 50 ms, statistics < 100 ms, full texture frame < 800 ms (the reference's CPU-mode ceilings)."""
+    r, fac, _, _ = sd_setup
+    assert _median_ms(r, lambda: r.generate_background(t=1.0)) < 500
+    assert _median_ms(r, lambda: r.accumulate_entity_layer(fac, now=1.0)) < 200
+    assert _median_ms(r, lambda: r.compose_interactive_texture()) < 50
+    assert _median_ms(r, lambda: r.recompute_interactive_stats()) < 100
+
+    def full():
+        r.generate_background(t=2.0)
+        r.accumulate_entity_layer(fac, now=2.0)
+        r.compose_interactive_texture()
+    ms = _median_ms(r, full)
+    assert ms < 800
+    assert ms < 20, f"texture frame took {ms:.1f} ms; this build's own budget is 20 ms at 640x360"
+
+
+def test_reference_texture_smoke_asserts(sd_setup):
+    """test_lifecycle_perf.py:145-201: structure, time dependence, no NaN/Inf, the render is not black."""
+    r, fac, cam, fov = sd_setup
+
+    def texture(t):
+        r.generate_background(t=t)
+        r.accumulate_entity_layer(fac, now=t)
+        r.recompute_interactive_stats()
+        r.compose_interactive_texture()
+        return r.disk_texture_field.to_numpy()
+
+    tex = texture(0.0)
+    assert tex[..., :3].std() > 0.01 and tex[..., 3].max() > 0.01 and tex[..., 3].std() > 0.001
+    later = texture(5.0)
+    assert np.abs(later - tex).mean() > 0.001
+    assert np.isfinite(tex).all() and np.isfinite(later).all()
+    img = r.render(cam, fov)
+    assert img.shape == (360, 640, 3) and img.max() > 0.01 and np.isfinite(img).all()
