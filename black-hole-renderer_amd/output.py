@@ -69,6 +69,10 @@ class FrameSink:
         self._renderer = renderer          # keeps the context alive
         _lib.check(self._lib.bhr_sink_create(renderer._ctx, slots, workers, level, C.byref(self._sink)))
         self.workers, self.slots, self.level = workers, slots, level
+        import weakref
+        if not hasattr(renderer, "_sinks"):
+            renderer._sinks = []
+        renderer._sinks.append(weakref.ref(self))
 
     def submit(self, path: str) -> None:
         _lib.check(self._lib.bhr_sink_submit(self._sink, os.fsencode(path)))

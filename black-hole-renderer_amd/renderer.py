@@ -94,6 +94,11 @@ class HipRenderer:
 
     # ------------------------------------------------------------------ lifetime
     def close(self) -> None:
+        for ref in getattr(self, "_sinks", []):      # frame sinks hold this context: drain and free them first
+            sink = ref()
+            if sink is not None:
+                sink.close()
+        self._sinks = []
         ctx, self._ctx = getattr(self, "_ctx", None), None
         if ctx:
             self._lib.bhr_destroy(ctx)

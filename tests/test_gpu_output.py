@@ -45,4 +45,9 @@ def test_sink_reports_write_errors(tmp_path):
     sink.close()
     with pytest.raises(ValueError):
         FrameSink(r, slots=1000)
-    r.close()
+    late = FrameSink(r, slots=2, workers=1)
+    r.render_async([6, 0, 0.5], 90)
+    late.submit(str(tmp_path / "late.png"))
+    r.close()                                                       # closing the renderer drains and frees its sinks
+    assert os.path.isfile(tmp_path / "late.png") and not late._sink
+    late.close()
