@@ -303,17 +303,54 @@ struct Shade {
 };
 // A disk crossing waiting to be shaded.  Crossings of the lanes of a wave are spread over several
 // RK4 steps (measured: ~6 wave-steps per tile see a hit, each with a handful of live lanes), and
-// shading is ~700 instructions, so a hit is parked here and shaded together with the other lanes'
-// hits: when some lane needs its slot for the NEXT hit (front-to-back order is kept; that lane
-// repeats its step afterwards) or when the wave has finished marching.  Results are unchanged --
-// the same operations run later.
+// shading is ~700 instructions, so a hit is parked and shaded together with the other lanes' hits.
+// Every lane has TWO parking slots: as soon as some lane has filled both, the wave shades the older
+// hit of every lane that has one (front-to-back order is kept) and the second slot moves up; the rest
+// is shaded when the wave has finished marching.  A lane can therefore always park the hit it finds,
+// a step never has to be repeated, and the ray state is committed unconditionally.  Results are
+// unchanged -- the same operations run later.
 template <bool DIFF>
 struct Pending {
     float hit_x, hit_y;
     V3 to_cam;
     float dxx, dxy, dyx, dyy;   // DIFF only
-    int valid;
 };
+// The two parking slots of every lane live in LDS (9 x 2 floats per lane, bank-conflict free: consecutive
+// lanes, consecutive words): they are touched a handful of times per ray, and in registers they cost the AA
+// kernel a wave of occupancy (128 -> 149 VGPRs).
+__shared__ float g_park[2][9][256];
+template <bool DIFF>
+__device__ __forceinline__ void park_store(int slot, const Pending<DIFF> &h) {
+    const int t = threadIdx.x;
+    g_park[slot][0][t] = h.hit_x;
+    g_park[slot][1][t] = h.hit_y;
+    g_park[slot][2][t] = h.to_cam.x;
+    g_park[slot][3][t] = h.to_cam.y;
+    g_park[slot][4][t] = h.to_cam.z;
+    if (DIFF) {
+        g_park[slot][5][t] = h.dxx;
+        g_park[slot][6][t] = h.dxy;
+        g_park[slot][7][t] = h.dyx;
+        g_park[slot][8][t] = h.dyy;
+    }
+}
+template <bool DIFF>
+__device__ __forceinline__ Pending<DIFF> park_load(int slot) {
+    const int t = threadIdx.x;
+    Pending<DIFF> h;
+    h.hit_x = g_park[slot][0][t];
+    h.hit_y = g_park[slot][1][t];
+    h.to_cam = mk(g_park[slot][2][t], g_park[slot][3][t], g_park[slot][4][t]);
+    if (DIFF) {
+        h.dxx = g_park[slot][5][t];
+        h.dxy = g_park[slot][6][t];
+        h.dyx = g_park[slot][7][t];
+        h.dyy = g_park[slot][8][t];
+    } else {
+        h.dxx = h.dxy = h.dyx = h.dyy = 0.0f;
+    }
+    return h;
+}
 template <bool DIFF, int SRC>
 __device__ __forceinline__ void shade_hit(const BhrMarchArgs &a, Shade &sh, float hit_x, float hit_y, V3 to_cam,
                                           float hdx_x, float hdx_y, float hdy_x, float hdy_y) {
@@ -448,11 +485,12 @@ struct Ray {
     float f_old;   // plane function at p
     float affine;
     Shade sh;
-    Pending<DIFF> pend;
+    int n_pend;    // parked disk crossings (0..2), in the lane's LDS slots, oldest first
     int step_count;
     int pix;       // linear pixel index inside the row block, -1 = lane has no ray
     int done;      // 0 running, 1 captured, 2 escaped, 3 ran out of iterations, 4 empty lane
-    V3 esc;
+    V3 esc;        // new_dir of an escaped ray (kRedo only; otherwise it is d)
+    Pending<DIFF> pendr;   // kRedo: the single parked crossing stays in registers
     V3 dpx, ddx, dpy, ddy;   // ray differentials (DIFF only)
 
     __device__ __forceinline__ void init(const BhrMarchArgs &a, int i, int j_local) {
@@ -468,7 +506,7 @@ struct Ray {
         affine = 0.0f;
         sh.accum = mk(0, 0, 0);
         sh.alpha_total = 0.0f;
-        pend.valid = 0;
+        n_pend = 0;
         step_count = 0;
         done = a.max_iter <= 0 ? 3 : 0;
         esc = mk(0, 0, 0);
@@ -492,7 +530,14 @@ struct Ray {
                   div6(fmaf(2.0f, k3.z, fmaf(2.0f, k2.z, k1.z)) + k4.z));
     }
 
-    // Returns false (nothing committed) when a hit finds the parking slot occupied; see the fast build.
+    // One iteration of the while-loop at render.py:2854-3006; false = nothing committed, repeat the step.
+    // Without differentials the state is committed unconditionally: a lane whose ray has terminated leaves
+    // the loop and never reads it again (escaped rays read d = new_dir), and with two parking slots a hit
+    // always finds room.  With differentials (128 VGPRs, at the edge of 4 waves per SIMD) the measured
+    // optimum is the opposite: ONE slot, a lane that finds it occupied returns false, the wave shades what
+    // is parked and the lane repeats its deterministic step; the guarded commit also keeps the scheduler
+    // from stretching live ranges across the whole step (4k AA: 6.7 ms against 7.6 ms unconditional).
+    static constexpr bool kRedo = DIFF;
     __device__ __forceinline__ bool step(const BhrMarchArgs &a) {
         float r_safe = fmaxf(r, BHR_RS + 1e-3f);
         float far_scale = sqrt_rn(r_safe);               // sqrt(r_safe / r_cap), r_cap = 1
@@ -569,20 +614,36 @@ struct Ray {
             float hy = p.y + t_frac * (np.y - p.y);
             float hit_r = sqrt_rn(hx * hx + hy * hy);
             if (a.r_outer >= hit_r && hit_r >= a.r_inner) {   // render.py:2951
-                if (pend.valid) return false;                 // slot occupied: flush, then repeat this step
-                pend.valid = 1;
-                pend.hit_x = hx;
-                pend.hit_y = hy;
-                pend.to_cam = mk(-d.x, -d.y, -d.z);           // direction at the START of the step (render.py:2954)
+                Pending<DIFF> h;
+                h.hit_x = hx;
+                h.hit_y = hy;
+                h.to_cam = mk(-d.x, -d.y, -d.z);              // direction at the START of the step (render.py:2954)
                 // the differentials were committed BEFORE the hit interpolation (render.py:2928-2932),
                 // hence hit_d_pos == new_d_pos in render.py:2947-2949
-                if (DIFF) { pend.dxx = ndpx.x; pend.dxy = ndpx.y; pend.dyx = ndpy.x; pend.dyy = ndpy.y; }
+                if (DIFF) { h.dxx = ndpx.x; h.dxy = ndpx.y; h.dyx = ndpy.x; h.dyy = ndpy.y; }
+                if (kRedo) {
+                    if (n_pend == 1) return false;            // slot occupied: flush, then repeat this step
+                    pendr = h;
+                } else {
+                    park_store<DIFF>(n_pend, h);              // a free slot is guaranteed (march_tile_kernel)
+                }
+                n_pend += 1;
             }
         }
         affine = aff;
-        if (escaped) esc = nd;
-        if (alive) {
-            if (DIFF) { dpx = ndpx; ddx = nddx; dpy = ndpy; ddy = nddy; }
+        if (kRedo) {
+            // the guarded commit of the single-slot scheme (see above); escaped rays keep new_dir in esc
+            if (escaped) esc = nd;
+            if (alive) {
+                if (DIFF) { dpx = ndpx; ddx = nddx; dpy = ndpy; ddy = nddy; }
+                p = np;
+                d = nd;
+                r = rn;
+                r2p = r2n;
+                f_old = f_new;
+                step_count += 1;
+            }
+        } else {
             p = np;
             d = nd;
             r = rn;
@@ -594,11 +655,16 @@ struct Ray {
         return true;
     }
 
-    __device__ __forceinline__ void shade_pending(const BhrMarchArgs &a) {
-        shade_hit<DIFF, SRC>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
-        pend.valid = 0;
+    // shade the oldest parked crossing (lanes that have one), the second slot moves up
+    __device__ __forceinline__ void flush_one(const BhrMarchArgs &a) {
+        if (n_pend > 0) {
+            const Pending<DIFF> h = kRedo ? pendr : park_load<DIFF>(0);
+            if (!kRedo && n_pend == 2) park_store<DIFF>(0, park_load<DIFF>(1));
+            n_pend -= 1;
+            shade_hit<DIFF, SRC>(a, sh, h.hit_x, h.hit_y, h.to_cam, h.dxx, h.dxy, h.dyx, h.dyy);
+        }
     }
-    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, esc, sh); }
+    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, kRedo ? esc : d, sh); }
 };
 
 #else
@@ -626,7 +692,7 @@ struct Ray {
     V3 g1, g2;            // in-plane orthonormal basis
     float affine;
     Shade sh;
-    Pending<DIFF> pend;
+    int n_pend;    // parked disk crossings (0..2), in the lane's LDS slots, oldest first
     int step_count;
     int pix;
     int done;
@@ -673,7 +739,7 @@ struct Ray {
         affine = 0.0f;
         sh.accum = mk(0, 0, 0);
         sh.alpha_total = 0.0f;
-        pend.valid = 0;
+        n_pend = 0;
         step_count = 0;
         done = a.max_iter <= 0 ? 3 : 0;
         pix = j_local * a.width + i;
@@ -716,10 +782,9 @@ struct Ray {
         return mk(fmaf(cu, g1.x, cw * g2.x), fmaf(cu, g1.y, cw * g2.y), fmaf(cu, g1.z, cw * g2.z));
     }
 
-    // One iteration of the while-loop at render.py:2854-3006.  Returns false when the step found a
-    // disk hit but the lane's parking slot still holds an unshaded earlier hit: nothing is committed,
-    // the wave shades its parked hits and the lane repeats the (deterministic) step.  Statement order
-    // keeps every state variable updated in place after its last use.
+    // One iteration of the while-loop at render.py:2854-3006.  Statement order keeps every state variable
+    // updated in place after its last use; the state is committed unconditionally (a terminated lane leaves
+    // the loop, an escaped ray reads (du, dw) back as new_dir).
     __device__ __forceinline__ bool step(const BhrMarchArgs &a) {
         // adaptive step (render.py:2858-2869) from 1/r:  q = 1/r_safe, sqrt(r_safe) = rsq(q)
         float q = fminf(ir, 1.0f / (BHR_RS + 1e-3f));
@@ -756,7 +821,7 @@ struct Ray {
         const bool escaped = !captured && (r2n > a.r_esc2 || aff > a.max_affine);
         const bool alive = !captured && !escaped;
         float f_new = Bn * nw;
-        bool redo = false;
+        bool hit_now = false;
         if (SRC == 2) {
             if (alive) volume_segment(a, sh, to3d(u, w), to3d(nu, nw), to3d(du, dw), f_old, f_new, q_rcp(ir), r2n * q_rsq(r2n));
         } else if (alive && f_old * f_new < 0) {
@@ -767,52 +832,56 @@ struct Ray {
             float hr2 = fmaf(hx, hx, hy * hy);
             float hit_r = hr2 * q_rsq(hr2);
             if (a.r_outer >= hit_r && hit_r >= a.r_inner) {   // render.py:2951
-                if (pend.valid) {
-                    redo = true;
-                } else {
-                    pend.valid = 1;
-                    pend.hit_x = hx;
-                    pend.hit_y = hy;
-                    V3 dir3 = to3d(du, dw);              // direction at the START of the step (render.py:2954)
-                    pend.to_cam = mk(-dir3.x, -dir3.y, -dir3.z);
-                }
+                V3 dir3 = to3d(du, dw);                  // direction at the START of the step (render.py:2954)
+                Pending<DIFF> h;
+                h.hit_x = hx;
+                h.hit_y = hy;
+                h.to_cam = mk(-dir3.x, -dir3.y, -dir3.z);
+                if (DIFF) h.dxx = h.dxy = h.dyx = h.dyy = 0.0f;   // attached below, once the new differentials exist
+                park_store<DIFF>(n_pend, h);                      // a free slot is guaranteed (march_tile_kernel)
+                n_pend += 1;
+                hit_now = true;
             }
         }
-        if (redo) return false;
         if (DIFF && alive) {
             // variational RK4 at the same four stage positions (render.py:2888-2911); the hit reads the
             // NEW differentials (committed before the plane test, render.py:2928-2932)
             float i2_1 = ir * ir;
             rk4_diff(dpx, ddx, h, hh, h6, s2u, s2w, s3u, s3w, s4u, s4w, c2, c3, c4, i2_1, i2_2, i2_3, i2_4);
             rk4_diff(dpy, ddy, h, hh, h6, s2u, s2w, s3u, s3w, s4u, s4w, c2, c3, c4, i2_1, i2_2, i2_3, i2_4);
-            if (pend.valid == 1) {                       // hit parked in THIS step: attach its footprint
+            if (hit_now) {                               // hit parked in THIS step: attach its footprint
                 V3 e3 = cross(g1, g2);
-                pend.dxx = dpx.x * g1.x + dpx.y * g2.x + dpx.z * e3.x;
-                pend.dxy = dpx.x * g1.y + dpx.y * g2.y + dpx.z * e3.y;
-                pend.dyx = dpy.x * g1.x + dpy.y * g2.x + dpy.z * e3.x;
-                pend.dyy = dpy.x * g1.y + dpy.y * g2.y + dpy.z * e3.y;
+                const float fxx = dpx.x * g1.x + dpx.y * g2.x + dpx.z * e3.x, fxy = dpx.x * g1.y + dpx.y * g2.y + dpx.z * e3.y;
+                const float fyx = dpy.x * g1.x + dpy.y * g2.x + dpy.z * e3.x, fyy = dpy.x * g1.y + dpy.y * g2.y + dpy.z * e3.y;
+                const int slot = n_pend - 1, t = threadIdx.x;
+                g_park[slot][5][t] = fxx;
+                g_park[slot][6][t] = fxy;
+                g_park[slot][7][t] = fyx;
+                g_park[slot][8][t] = fyy;
             }
         }
-        if (pend.valid == 1) pend.valid = 2;             // 1 = parked in this step, 2 = parked earlier
         affine = aff;
         du = fmaf(h6, sdu, du);                          // escaped rays read these back as the escape
         dw = fmaf(h6, sdw, dw);                          // direction = new_dir (render.py:2921)
-        if (alive) {
-            u = nu;
-            w = nw;
-            ir = q_rsq(r2n);
-            float i2 = ir * ir;
-            c1 = m15L2 * (i2 * i2 * ir);
-            f_old = f_new;
-            step_count += 1;
-        }
+        u = nu;
+        w = nw;
+        ir = q_rsq(r2n);
+        float i2 = ir * ir;
+        c1 = m15L2 * (i2 * i2 * ir);
+        f_old = f_new;
+        step_count += 1;
         done = captured ? 1 : (escaped ? 2 : (step_count >= a.max_iter ? 3 : 0));
-        return true;
+        return true;     // two parking slots: a step never has to be repeated
     }
 
-    __device__ __forceinline__ void shade_pending(const BhrMarchArgs &a) {
-        shade_hit<DIFF, SRC>(a, sh, pend.hit_x, pend.hit_y, pend.to_cam, pend.dxx, pend.dxy, pend.dyx, pend.dyy);
-        pend.valid = 0;
+    // shade the oldest parked crossing (lanes that have one), the second slot moves up
+    __device__ __forceinline__ void flush_one(const BhrMarchArgs &a) {
+        if (n_pend > 0) {
+            const Pending<DIFF> h = park_load<DIFF>(0);
+            if (n_pend == 2) park_store<DIFF>(0, park_load<DIFF>(1));
+            n_pend -= 1;
+            shade_hit<DIFF, SRC>(a, sh, h.hit_x, h.hit_y, h.to_cam, h.dxx, h.dxy, h.dyx, h.dyy);
+        }
     }
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, to3d(du, dw), sh); }
 };
@@ -832,6 +901,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // ring) evenly.  An XCD-banded remap was measured and rejected (-13 %: the kernel is VALU
 // bound, texture traffic is negligible, and bands of rows differ in cost).
 // ---------------------------------------------------------------------------
+// The texture kernels are held to 128 VGPRs (4 waves per SIMD): the strict arithmetic is a chain of dependent
+// exact-rounding sequences and needs the waves to cover its latency (measured at 4k with AA: 141 VGPRs / 3 waves
+// 7.6 ms, 128 / 4 waves 6.7 ms).  The binary64 Disk V2 instantiations take what they need.
 template <bool DIFF, int SRC = 0>
 __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     const int lane = threadIdx.x & 63;
@@ -852,13 +924,12 @@ __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     while (ray.done == 0) {
         const bool blocked = !ray.step(a);
         executed += blocked ? 0u : 1u;
-        // some live lane found its parking slot occupied: the live lanes shade what they have parked,
-        // that lane then repeats its step
-        if (__ballot(blocked)) {
-            if (ray.pend.valid) ray.shade_pending(a);
-        }
+        // some live lane has filled its parking slots (or, strict AA, found its only slot occupied and will
+        // repeat the step): every live lane shades its older crossing
+        if (__ballot(blocked || ray.n_pend == 2)) ray.flush_one(a);
     }
-    if (ray.pend.valid) ray.shade_pending(a);
+    if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
+    if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
     if (valid) ray.finish(a);
     unsigned long long tot = wave_sum_u32(executed);
     if (lane == 0) atomicAdd(a.ray_steps, tot);
@@ -893,7 +964,10 @@ __global__ __launch_bounds__(256) void march_persistent_kernel(BhrMarchArgs a, i
         int n_live = __popcll(live);
         if (!queue_empty && n_live < refill_below) {
             // retire finished lanes, then hand every non-running lane a new pixel
-            if (ray.pend.valid && ray.done != 0) ray.shade_pending(a);
+            for (int k = 0; k < 2; ++k)
+                if (__ballot(ray.n_pend > 0 && ray.done != 0)) {
+                    if (ray.done != 0) ray.flush_one(a);
+                }
             if (ray.done >= 1 && ray.done <= 3) ray.finish(a);
             unsigned long long want = ~live;
             int n_want = 64 - n_live;
@@ -914,7 +988,8 @@ __global__ __launch_bounds__(256) void march_persistent_kernel(BhrMarchArgs a, i
             continue;
         }
         if (!live) {
-            if (ray.pend.valid) ray.shade_pending(a);
+            for (int k = 0; k < 2; ++k)
+                if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
             if (ray.done >= 1 && ray.done <= 3) ray.finish(a);
             break;
         }
@@ -923,9 +998,7 @@ __global__ __launch_bounds__(256) void march_persistent_kernel(BhrMarchArgs a, i
             blocked = !ray.step(a);
             executed += blocked ? 0u : 1u;
         }
-        if (__ballot(blocked)) {
-            if (ray.pend.valid) ray.shade_pending(a);
-        }
+        if (__ballot(blocked || ray.n_pend == 2)) ray.flush_one(a);
     }
     unsigned long long tot = wave_sum_u32(executed);
     if (lane == 0) atomicAdd(a.ray_steps, tot);
