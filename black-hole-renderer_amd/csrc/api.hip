@@ -61,6 +61,25 @@ __global__ void quantize_u8_kernel(const float *__restrict__ src, uint8_t *__res
     for (; i < n; i += stride) dst[i] = (uint8_t)(int)(fminf(fmaxf(src[i], 0.0f), 1.0f) * 255.0f);
 }
 
+// sum of the lanes of `n` counter cells -> host
+__global__ void steps_fold_kernel(const unsigned long long *__restrict__ cells, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long sh[BHR_STEP_LANES];
+    sh[threadIdx.x] = cells[(size_t)blockIdx.x * BHR_STEP_CELL + (size_t)threadIdx.x * BHR_STEP_STRIDE];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int k = 0; k < BHR_STEP_LANES; ++k) t += sh[k];
+        out[blockIdx.x] = t;
+    }
+}
+int32_t fold_cells(bhr_ctx *ctx, const unsigned long long *cells, int n, unsigned long long *host_out) {
+    hipLaunchKernelGGL(steps_fold_kernel, dim3(n), dim3(BHR_STEP_LANES), 0, ctx->stream, cells, ctx->d_steps_fold);
+    BHR_HIP(hipGetLastError());
+    BHR_HIP(hipMemcpyAsync(host_out, ctx->d_steps_fold, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, ctx->stream));
+    BHR_HIP(hipStreamSynchronize(ctx->stream));
+    return BHR_OK;
+}
+
 }  // namespace
 
 // FINAL (f32) -> d_final_u8 on the context's stream
@@ -174,11 +193,12 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     if ((rc = dev_alloc(&ctx->d_wext, 3 * (2 * (R + 4) + 8)))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_wsum_h, 3 * W))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_wsum_v, 3 * H))) return bail(rc);
-    if ((rc = dev_alloc(&ctx->d_ray_steps, 1))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_ray_steps, BHR_STEP_CELL))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_queue, 1))) return bail(rc);
-    if ((rc = dev_alloc(&ctx->d_steps_ring, BHR_TIMING_RING))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_steps_ring, (size_t)BHR_TIMING_RING * BHR_STEP_CELL))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_steps_fold, BHR_TIMING_RING))) return bail(rc);
     if (hipMemsetAsync(ctx->d_hblur, 0, 3 * (rows + 2 * R) * W * sizeof(float), ctx->stream) != hipSuccess ||
-        hipMemsetAsync(ctx->d_ray_steps, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess)
+        hipMemsetAsync(ctx->d_ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream) != hipSuccess)
         return bail(bhr_fail(BHR_ERR_HIP, "hipMemsetAsync failed"));
     int32_t v = 0, l = 0;
     if (cfg->math_mode != BHR_MATH_FAST && cfg->math_mode != BHR_MATH_STRICT)
@@ -201,7 +221,7 @@ void bhr_destroy(bhr_ctx *ctx) {
     free_bg(ctx);
     void *bufs[] = {ctx->d_skybox, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_final_u8, ctx->d_hblur,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_queue, ctx->d_noise_in,
-                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params, ctx->d_glow_hw, ctx->d_glow_wh,
+                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params, ctx->d_glow_hw, ctx->d_glow_wh,
                     ctx->d_flare_c0, ctx->d_flare_c12, ctx->d_flare_prog, ctx->d_flare_sums};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -484,7 +504,7 @@ int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {
     BHR_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->timing_valid) {
         unsigned long long steps = 0;
-        BHR_HIP(hipMemcpy(&steps, ctx->last_steps_ptr ? ctx->last_steps_ptr : ctx->d_ray_steps, sizeof(steps), hipMemcpyDeviceToHost));
+        BHR_TRY(fold_cells(ctx, ctx->last_steps_ptr ? ctx->last_steps_ptr : ctx->d_ray_steps, 1, &steps));
         ctx->counters.ray_steps = steps;
         ctx->counters.march_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
         ctx->counters.bloom_ms = ev_ms(ctx->ev[1], ctx->ev[2]);
@@ -496,7 +516,7 @@ int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {
         unsigned long long steps_sum = 0;
         if (n > 0) {
             std::vector<unsigned long long> hs(BHR_TIMING_RING);
-            BHR_HIP(hipMemcpy(hs.data(), ctx->d_steps_ring, sizeof(unsigned long long) * BHR_TIMING_RING, hipMemcpyDeviceToHost));
+            BHR_TRY(fold_cells(ctx, ctx->d_steps_ring, BHR_TIMING_RING, hs.data()));
             for (int64_t k = 0; k < n; ++k) {
                 const int slot = (int)((ctx->ring_head - 1 - k) % BHR_TIMING_RING);
                 ms_m += ev_ms(ctx->ring_ev[slot * 3 + 0], ctx->ring_ev[slot * 3 + 1]);

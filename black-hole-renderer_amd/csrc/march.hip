@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
     if (valid) ray.finish(a);
     unsigned long long tot = wave_sum_u32(executed);
-    if (lane == 0) atomicAdd(a.ray_steps, tot);
+    if (lane == 0) atomicAdd(a.ray_steps + (size_t)(blockIdx.x & (BHR_STEP_LANES - 1)) * BHR_STEP_STRIDE, tot);
 }
 
 // ---------------------------------------------------------------------------
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(256) void march_persistent_kernel(BhrMarchArgs a, i
         if (__ballot(blocked || ray.n_pend == 2)) ray.flush_one(a);
     }
     unsigned long long tot = wave_sum_u32(executed);
-    if (lane == 0) atomicAdd(a.ray_steps, tot);
+    if (lane == 0) atomicAdd(a.ray_steps + (size_t)(blockIdx.x & (BHR_STEP_LANES - 1)) * BHR_STEP_STRIDE, tot);
 }
 
 #if BHR_MARCH_STRICT
@@ -1118,7 +1118,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     a.disk = ctx->d_disk;
     // timed launches (bhr_render) count into their ring slot; group launches into the scalar
     const int slot = ctx->cur_slot;
-    a.ray_steps = slot >= 0 ? ctx->d_steps_ring + slot : ctx->d_ray_steps;
+    a.ray_steps = slot >= 0 ? ctx->d_steps_ring + (size_t)slot * BHR_STEP_CELL : ctx->d_ray_steps;
     a.queue = ctx->d_queue;
     a.dv2 = ctx->disk_source != BHR_DISK_TEXTURE ? ctx->d_dv2_params : nullptr;
     a.vol_absorption = ctx->vol_opts[0];
@@ -1136,7 +1136,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     // the CLI path) but never reads them (render.py:2957-2959) => skipping them is pixel-identical.
     const bool want_diff = c.anti_alias != 0 && !(flags & BHR_SKIP_DIFFERENTIALS);
 
-    BHR_HIP(hipMemsetAsync(a.ray_steps, 0, sizeof(unsigned long long), ctx->stream));
+    BHR_HIP(hipMemsetAsync(a.ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream));
     if (flags & BHR_PERSISTENT) BHR_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned int), ctx->stream));
     BHR_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (slot >= 0) BHR_HIP(hipEventRecord(ctx->ring_ev[slot * 3 + 0], ctx->stream));
