@@ -107,6 +107,8 @@ def main(argv=None) -> int:
         rank = int(os.environ.get("RANK", "0"))
         world = int(os.environ.get("WORLD_SIZE", "1"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if "BHR_FORCE_DEVICE" in os.environ:        # rehearsal: several ranks sharing one card
+            local_rank = int(os.environ["BHR_FORCE_DEVICE"])
         renderer, _, _, _ = drivers.make_renderer(
             width, height, args.pov, fov, args.step_size, args.texture, args.n_stars, 2048, 1024, args.r_max, None,
             args.disk_inner_radius, args.disk_outer_radius, args.disk_tilt, args.lens_flare, args.anti_alias,

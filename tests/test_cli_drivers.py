@@ -183,3 +183,34 @@ def test_cli_end_to_end(tmp_path):
     from PIL import Image
     img = np.array(Image.open(out))
     assert img.shape == (360, 640, 3) and img.max() > 50
+
+
+@pytest.mark.gpu
+def test_cli_video_two_ranks_under_torchrun(tmp_path):
+    """configs[4] as it is launched on a node: `torch.distributed.run ... render.py --video --orbit`, frames
+    f % 2 == rank, a gloo barrier, rank 0 merges the progress files.  Both ranks share the card here
+    (BHR_FORCE_DEVICE); the frames equal those of a single-process run."""
+    import json
+    from PIL import Image
+    from bhr_amd import drivers
+    common = ["-r", "sd", "--n_stars", "100", "--video", "--orbit", "--n_frames", "6", "--orbit_degrees", "60", "--fps", "6"]
+    out2 = tmp_path / "two" / "v.mp4"
+    env = dict(os.environ, BHR_FORCE_DEVICE="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "render.py"),
+                        *common, "-o", str(out2)], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    d2 = drivers._frames_dir(str(out2))
+    done = set()
+    for r in range(2):
+        done |= set(json.load(open(os.path.join(d2, f"progress.rank{r}.json")))["completed"])
+    assert done == set(range(6))
+    out1 = tmp_path / "one" / "v.mp4"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "render.py"), *common, "-o", str(out1)],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert p.returncode == 0, p.stderr[-1500:]
+    d1 = drivers._frames_dir(str(out1))
+    for k in range(6):
+        a = np.array(Image.open(os.path.join(d1, f"frame_{k:04d}.png")))
+        b = np.array(Image.open(os.path.join(d2, f"frame_{k:04d}.png")))
+        np.testing.assert_array_equal(a, b)
