@@ -214,3 +214,24 @@ def test_cli_video_two_ranks_under_torchrun(tmp_path):
         a = np.array(Image.open(os.path.join(d1, f"frame_{k:04d}.png")))
         b = np.array(Image.open(os.path.join(d2, f"frame_{k:04d}.png")))
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    """bench.py's N > 1 path (barrier, max-over-ranks time, summed ray-steps, one JSON line from rank 0) with two
+    gloo ranks sharing the card; RCCL itself refuses two ranks on one device, its init is covered by the
+    BHR_DIST_FORCE single-rank run in DESIGN.md."""
+    import json
+    env = dict(os.environ, BHR_DIST_BACKEND="gloo", BHR_FORCE_DEVICE="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29534", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "3", "--workload", "sd", "--no-other-math"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                       # exactly one line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["metric"] == "Mray-steps/s"
+    per_frame = d["config"]["ray_steps_per_frame"]
+    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * 20 / (2 * 20 * per_frame) - 1) < 1e-6   # value = all ranks' steps / time
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
