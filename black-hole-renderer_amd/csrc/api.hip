@@ -222,7 +222,7 @@ void bhr_destroy(bhr_ctx *ctx) {
     void *bufs[] = {ctx->d_skybox, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_final_u8, ctx->d_hblur,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_queue, ctx->d_noise_in,
                     ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params, ctx->d_glow_hw, ctx->d_glow_wh,
-                    ctx->d_flare_c0, ctx->d_flare_c12, ctx->d_flare_prog, ctx->d_flare_sums};
+                    ctx->d_flare_c0, ctx->d_flare_c12, ctx->d_flare_prog, ctx->d_flare_sums, ctx->d_tile_order, ctx->d_row_steps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -546,6 +546,16 @@ int32_t bhr_selftest(bhr_ctx *ctx, uint64_t out[4]) {
     if (rc == BHR_OK) rc = download(ctx, out, d, 4 * sizeof(unsigned long long));
     (void)hipFree(d);
     return rc;
+}
+
+int32_t bhr_get_row_costs(bhr_ctx *ctx, uint64_t *out, int32_t n) {
+    if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_get_row_costs: bad argument");
+    const int32_t bands = (ctx->rows + 7) / 8;
+    if (n != bands) return bhr_fail(BHR_ERR_INVALID, "bhr_get_row_costs: the context has %d 8-row bands, caller asked for %d", bands, n);
+    if (!ctx->d_row_steps || !(ctx->last_flags & BHR_ROW_COSTS))
+        return bhr_fail(BHR_ERR_STATE, "bhr_get_row_costs: the last bhr_render did not carry BHR_ROW_COSTS");
+    BHR_TRY(use_device(ctx));
+    return download(ctx, out, ctx->d_row_steps, (size_t)bands * sizeof(uint64_t));
 }
 
 int32_t bhr_timing_reset(bhr_ctx *ctx) {

@@ -29,6 +29,7 @@
 #define BHR_STEP_STRIDE 32          // in u64 words
 #define BHR_STEP_CELL (BHR_STEP_LANES * BHR_STEP_STRIDE)
 
+#define BHR_FLUSH_COST 5u            // cost of one wave-wide shading pass in wave-steps (row-cost profile)
 #define BHR_VOLUME_OPAQUE 0.9999f   // finite-thickness disk: accumulated opacity at which a ray stops sampling
 
 #define BHR_PI_F 3.14159274101257324f      // (float)pi
@@ -66,6 +67,8 @@ struct BhrMarchArgs {
     double dv2_norm_shear, dv2_norm_hotspot, dv2_t_peak;
     double vol_absorption, vol_grazing_gain, vol_h_max, vol_r_max;   // finite-thickness Disk V2
     int32_t vol_substeps;
+    const int32_t *tile_order;   // launch slot -> tile (nullptr: row-major)
+    unsigned long long *row_steps;   // BHR_ROW_COSTS: ray-steps per 8-row band (nullptr: not collected)
     int32_t n_tiles;         // 8x8 pixel tiles in the row block
     int32_t tiles_x;
 };
@@ -127,6 +130,9 @@ struct bhr_ctx {
     int32_t bloom_R, bloom_ready;
     unsigned long long *d_ray_steps;
     unsigned int *d_queue;
+    unsigned long long *d_row_steps;   // ray-steps per 8-row band of the last BHR_ROW_COSTS launch
+    int32_t *d_tile_order;     // march launch order of the 8x8 tiles
+    int32_t tile_order_n;
     // lens flare (flare.hip)
     float *d_glow_hw;          // glow rows (rows, W); (H, W) on the context that sums the frame
     int64_t flare_glow_rows;

@@ -32,6 +32,10 @@
 #include <stdlib.h>
 
 #include "bhr_internal.h"
+
+#include <algorithm>
+#include <utility>
+#include <vector>
 #include "disk_v2_device.h"
 
 #ifndef BHR_MARCH_STRICT
@@ -908,7 +912,10 @@ template <bool DIFF, int SRC = 0>
 __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     const int lane = threadIdx.x & 63;
     // one 8x8 tile per wave, tiles in row-major order; blockDim.x / 64 waves per block
-    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // tiles are handed out longest first (tile_order: by distance from the image of the hole, where rays take the
+    // most steps), so that the launch does not end on a few late, long waves
+    const int tile = (a.tile_order && slot < a.n_tiles) ? a.tile_order[slot] : slot;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int i = tx * 8 + (lane & 7);
     const int j = ty * 8 + (lane >> 3);
@@ -921,18 +928,24 @@ __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     // Divergent loop: a lane leaves when its ray terminates, the wave leaves when its EXEC mask is
     // empty (the hardware form of "loop while __ballot(alive)").  Written without an inner `if` because
     // hipcc otherwise shuttles the whole ray state through v_mov at every iteration (24 moves/step).
+    unsigned int flushes = 0;     // wave-uniform
     while (ray.done == 0) {
         const bool blocked = !ray.step(a);
         executed += blocked ? 0u : 1u;
         // some live lane has filled its parking slots (or, strict AA, found its only slot occupied and will
         // repeat the step): every live lane shades its older crossing
-        if (__ballot(blocked || ray.n_pend == 2)) ray.flush_one(a);
+        if (__ballot(blocked || ray.n_pend == 2)) { ray.flush_one(a); flushes += 1u; }
     }
-    if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
-    if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
+    if (__ballot(ray.n_pend > 0)) { ray.flush_one(a); flushes += 1u; }
+    if (__ballot(ray.n_pend > 0)) { ray.flush_one(a); flushes += 1u; }
     if (valid) ray.finish(a);
     unsigned long long tot = wave_sum_u32(executed);
-    if (lane == 0) atomicAdd(a.ray_steps + (size_t)(blockIdx.x & (BHR_STEP_LANES - 1)) * BHR_STEP_STRIDE, tot);
+    if (lane == 0) {
+        atomicAdd(a.ray_steps + (size_t)(blockIdx.x & (BHR_STEP_LANES - 1)) * BHR_STEP_STRIDE, tot);
+        // BHR_ROW_COSTS: cost profile over tile rows = ray-steps + the wave's shading passes, each priced as
+        // BHR_FLUSH_COST wave-steps (a pass is ~1000 instructions, a strict step ~220)
+        if (a.row_steps && tile < a.n_tiles) atomicAdd(a.row_steps + ty, tot + (unsigned long long)flushes * (64u * BHR_FLUSH_COST));
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1049,6 +1062,28 @@ int32_t bhr_selftest_strict(bhr_ctx *ctx, unsigned long long *d_out4) {
 }
 #endif
 
+// Tile order of this context: 8x8 tiles sorted by the distance of their centre from the centre of the FULL
+// image (the camera looks at the hole, build_camera), nearest first.  Built once per context.
+static int32_t ensure_tile_order(bhr_ctx *ctx, int tiles_x, int n_tiles) {
+    if (ctx->d_tile_order && ctx->tile_order_n == n_tiles) return BHR_OK;
+    if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
+    ctx->d_tile_order = nullptr;
+    std::vector<std::pair<float, int>> key((size_t)n_tiles);
+    const float cx = 0.5f * (float)ctx->cfg.width, cy = 0.5f * (float)ctx->cfg.height;
+    for (int t = 0; t < n_tiles; ++t) {
+        const float x = (float)((t % tiles_x) * 8 + 4) - cx, y = (float)(ctx->cfg.row0 + (t / tiles_x) * 8 + 4) - cy;
+        key[(size_t)t] = {x * x + y * y, t};
+    }
+    std::stable_sort(key.begin(), key.end(),
+                     [](const std::pair<float, int> &l, const std::pair<float, int> &r) { return l.first < r.first; });
+    std::vector<int32_t> order((size_t)n_tiles);
+    for (int t = 0; t < n_tiles; ++t) order[(size_t)t] = key[(size_t)t].second;
+    BHR_HIP(hipMalloc((void **)&ctx->d_tile_order, (size_t)n_tiles * sizeof(int32_t)));
+    BHR_HIP(hipMemcpy(ctx->d_tile_order, order.data(), (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
+    ctx->tile_order_n = n_tiles;
+    return BHR_OK;
+}
+
 int32_t BHR_MARCH_RESOURCES(int32_t *vgprs, int32_t *lds, int32_t diff) {
     hipFuncAttributes at;
     const void *f = diff ? (const void *)march_tile_kernel<true, 0> : (const void *)march_tile_kernel<false, 0>;
@@ -1131,6 +1166,21 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     a.dv2_t_peak = ctx->dv2_norm[2];
     a.tiles_x = (c.width + 7) / 8;
     a.n_tiles = a.tiles_x * ((ctx->rows + 7) / 8);
+    a.row_steps = nullptr;
+    if (flags & BHR_ROW_COSTS) {
+        const size_t n = (size_t)((ctx->rows + 7) / 8);
+        if (!ctx->d_row_steps) BHR_HIP(hipMalloc((void **)&ctx->d_row_steps, n * sizeof(unsigned long long)));
+        BHR_HIP(hipMemsetAsync(ctx->d_row_steps, 0, n * sizeof(unsigned long long), ctx->stream));
+        a.row_steps = ctx->d_row_steps;
+    }
+    a.tile_order = nullptr;
+    {
+        const char *e = getenv("BHR_TILE_ORDER");          // "centre" (default) | "row": row-major, for A/B runs
+        if (!(e && e[0] == 'r')) {
+            BHR_TRY(ensure_tile_order(ctx, a.tiles_x, a.n_tiles));
+            a.tile_order = ctx->d_tile_order;
+        }
+    }
 
     // anti_alias "disabled": the reference still integrates the differentials (skip_diff = 0 on
     // the CLI path) but never reads them (render.py:2957-2959) => skipping them is pixel-identical.
@@ -1140,7 +1190,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     if (flags & BHR_PERSISTENT) BHR_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned int), ctx->stream));
     BHR_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (slot >= 0) BHR_HIP(hipEventRecord(ctx->ring_ev[slot * 3 + 0], ctx->stream));
-    if (!(flags & BHR_PERSISTENT) || a.dv2) {   // the persistent schedule has no Disk V2 instantiation
+    if (!(flags & BHR_PERSISTENT) || a.dv2 || a.row_steps) {   // the persistent schedule has no Disk V2 / row-cost variant
         // waves per block: a block keeps its CU slot until its slowest wave has finished, so small
         // blocks shorten the tail; BHR_TILE_BLOCK overrides for experiments
         int bt = 256;

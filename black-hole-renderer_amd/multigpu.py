@@ -28,6 +28,52 @@ def row_blocks(height: int, n: int) -> List[Tuple[int, int]]:
     return cuts
 
 
+def balanced_row_blocks(height: int, n: int, band_costs: Sequence[float], band_rows: int, quantum: int = 8,
+                        fixed_cost_per_row: float = 0.0) -> List[Tuple[int, int]]:
+    """n contiguous row blocks of about equal COST.  ``band_costs[k]`` is the cost (ray-steps) of rows
+    [k * band_rows, (k + 1) * band_rows) of the image; cuts fall on multiples of ``quantum`` rows (the march works
+    in 8x8 tiles) and every block gets at least one quantum.  ``fixed_cost_per_row`` adds a per-row constant
+    (set-up and shading work that does not scale with the step count)."""
+    if n < 1 or n * quantum > height:
+        raise ValueError(f"cannot cut {height} rows into {n} blocks of at least {quantum} rows")
+    costs = np.asarray(band_costs, dtype=np.float64)
+    if costs.ndim != 1 or len(costs) * band_rows < height or (costs < 0).any():
+        raise ValueError("band_costs must be non-negative and cover the image")
+    per_row = np.repeat(costs / band_rows, band_rows)[:height] + fixed_cost_per_row
+    if per_row.sum() <= 0:
+        return row_blocks(height, n)
+    cum = np.concatenate([[0.0], np.cumsum(per_row)])
+    cuts = [0]
+    for k in range(1, n):
+        target = cum[-1] * k / n
+        r = int(np.searchsorted(cum, target))
+        r = int(round(r / quantum)) * quantum
+        lo = cuts[-1] + quantum                                   # at least one quantum per block ...
+        hi = height - (n - k) * quantum                           # ... including the blocks still to come
+        cuts.append(min(max(r, lo), hi))
+    cuts.append(height)
+    return [(cuts[k], cuts[k + 1]) for k in range(n)]
+
+
+def probe_row_costs(width: int, height: int, cam_pos, fov: float, scale: int = 8, device_index: int = 0, **kw):
+    """(band_costs, band_rows) of a width x height frame from a frame ``scale`` times smaller: the number of
+    steps a ray takes depends on the camera, the step size and the escape radius, not on the textures, so the
+    probe runs with placeholder textures (a fraction of a millisecond)."""
+    from .renderer import HipRenderer
+    keep = {k: kw[k] for k in ("step_size", "r_max", "r_disk_inner", "r_disk_outer", "disk_tilt") if k in kw}
+    pw, ph = max(8, width // scale), max(8, height // scale)
+    probe = HipRenderer(pw, ph, np.zeros((8, 16, 3), np.float32), np.zeros((32, 64, 4), np.float32),
+                        device_index=device_index, math="fast", **keep)
+    try:
+        costs = probe.row_costs(cam_pos, fov).astype(np.float64)
+    finally:
+        probe.close()
+    band_rows = 8 * height / ph                                   # probe band of 8 rows -> rows of the full image
+    # resample onto whole rows of the full image
+    per_row = np.interp((np.arange(height) + 0.5) / band_rows, np.arange(len(costs)) + 0.5, costs / band_rows)
+    return per_row, 1
+
+
 def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
     """Round-robin frame shard of BASELINE.json configs[4]."""
     return range(rank, n_frames, world)
@@ -49,9 +95,10 @@ def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_diff
     return out
 
 
-def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devices=None, **kw) -> np.ndarray:
+def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devices=None, balance=True, **kw) -> np.ndarray:
     """render_image over ``gpus`` row blocks.  ``devices`` maps block k to a HIP device ordinal
-    (default k); every device builds the same deterministic scene."""
+    (default k); every device builds the same deterministic scene.  ``balance``: cut the rows by the cost
+    profile of a probe frame (rows through the shadow and the photon ring take more steps) instead of evenly."""
     from .drivers import make_renderer, init_lifecycle_system, advance_lifecycle_frame, use_analytic_disk
     disk_model = kw.pop("disk_model", "texture")
     if devices is None and os.environ.get("BHR_TILE_DEVICES"):     # e.g. "0,0": rehearse two tiles on one card
@@ -59,8 +106,12 @@ def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devi
     devices = list(range(gpus)) if devices is None else list(devices)
     if len(devices) != gpus:
         raise ValueError(f"{gpus} row blocks need {gpus} device ordinals, got {devices}")
+    blocks = row_blocks(height, gpus)
+    if balance and gpus > 1 and height >= 64 * gpus:
+        per_row, band_rows = probe_row_costs(width, height, cam_pos, fov, device_index=devices[0], **kw)
+        blocks = balanced_row_blocks(height, gpus, per_row, band_rows, fixed_cost_per_row=0.1 * float(per_row.mean()))
     tiles = []
-    for k, rows in enumerate(row_blocks(height, gpus)):
+    for k, rows in enumerate(blocks):
         r, use_lifecycle, n_r, n_phi = make_renderer(width, height, cam_pos, fov, device_index=devices[k],
                                                      rows=rows, lens_flare=False, **kw)
         if use_analytic_disk(r, disk_model):

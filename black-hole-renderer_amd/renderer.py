@@ -366,6 +366,15 @@ class HipRenderer:
         _lib.check(self._lib.bhr_lens_flare_sums(self._ctx, out))
         return np.array(out[:], dtype=np.float64)
 
+    def row_costs(self, cam_pos, fov: float) -> np.ndarray:
+        """Ray-steps per band of 8 rows for this view (one march with BHR_ROW_COSTS, no bloom)."""
+        cam = self.camera_uniforms(cam_pos, fov, 0)
+        flags = self._flags(True, True) | _lib.ROW_COSTS
+        _lib.check(self._lib.bhr_render(self._ctx, C.byref(cam), flags))
+        out = np.zeros((self.rows + 7) // 8, dtype=np.uint64)
+        _lib.check(self._lib.bhr_get_row_costs(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)), len(out)))
+        return out
+
     def read_final_u8(self) -> np.ndarray:
         out = np.empty((self.rows, self.width, 3), dtype=np.uint8)
         _lib.check(self._lib.bhr_read_final_u8(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8))))

@@ -90,6 +90,7 @@ typedef struct {
 #define BHR_PERSISTENT         4u  /* persistent waves + queue refill instead of the tile schedule */
 #define BHR_FORCE_FAST         8u  /* this call only: fast arithmetic regardless of bhr_config.math_mode */
 #define BHR_FORCE_STRICT      16u  /* this call only: strict arithmetic regardless of bhr_config.math_mode */
+#define BHR_ROW_COSTS         64u  /* also accumulate ray-steps per 8-row band (bhr_get_row_costs): the cost profile row blocks are balanced with */
 #define BHR_LENS_FLARE        32u  /* add the lens flare to the final layer on the device (render.py:3920-4028) */
 
 /* selectors for bhr_read_layer */
@@ -204,6 +205,11 @@ BHR_API int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out);
 BHR_API int32_t bhr_selftest(bhr_ctx *ctx, uint64_t out[4]);
 /* forget the per-frame timing ring (call before a timed region) */
 BHR_API int32_t bhr_timing_reset(bhr_ctx *ctx);
+/* Cost of each band of 8 rows in the last bhr_render(..., BHR_ROW_COSTS), in ray-step units: the ray-steps marched
+ * plus 320 per wave-wide shading pass.  n = ceil(rows / 8) values.
+ * The step count of a ray depends on the camera, the step size and the escape radius only -- not on the
+ * textures -- so a small probe frame gives the cost profile of a large one (multigpu.balanced_row_blocks). */
+BHR_API int32_t bhr_get_row_costs(bhr_ctx *ctx, uint64_t *out, int32_t n);
 
 /* ---- multi-GPU row-block tiling (one process driving N devices) -----------
  * ctxs[k] renders rows [row0_k,row1_k) of the same image; blocks must be

@@ -235,3 +235,58 @@ def test_bench_two_ranks_rehearsal():
     per_frame = d["config"]["ray_steps_per_frame"]
     assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * 20 / (2 * 20 * per_frame) - 1) < 1e-6   # value = all ranks' steps / time
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+
+
+def test_balanced_row_blocks_properties():
+    from bhr_amd.multigpu import balanced_row_blocks, row_blocks
+    rng = np.random.default_rng(0)
+    for height, n in ((4320, 8), (1080, 8), (360, 3), (64, 8), (1000, 7)):
+        bands = -(-height // 8)
+        cost = 1.0 + 3.0 * np.exp(-((np.arange(bands) - bands / 2) / (bands / 6)) ** 2) + 0.05 * rng.random(bands)
+        blocks = balanced_row_blocks(height, n, cost, 8)
+        assert blocks[0][0] == 0 and blocks[-1][1] == height and len(blocks) == n
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))                       # contiguous, ordered
+        assert all(r0 % 8 == 0 for r0, _ in blocks) and all(r1 - r0 >= 8 for r0, r1 in blocks)
+        per_row = np.repeat(cost / 8, 8)[:height]
+        got = np.array([per_row[r0:r1].sum() for r0, r1 in blocks])
+        even = np.array([per_row[r0:r1].sum() for r0, r1 in row_blocks(height, n)])
+        if height >= 64 * n:
+            assert got.max() <= even.max() + 1e-9 and got.max() / got.mean() < 1.10       # better than an even cut
+    assert balanced_row_blocks(360, 3, np.zeros(45), 8) == row_blocks(360, 3)               # no information: even cut
+    with pytest.raises(ValueError):
+        balanced_row_blocks(40, 8, np.ones(5), 8)
+    with pytest.raises(ValueError):
+        balanced_row_blocks(360, 3, np.ones(10), 8)
+
+
+@pytest.mark.gpu
+def test_row_costs_and_balanced_tiles():
+    """The per-band step profile adds up to the frame's ray-steps, does not depend on the textures, and row blocks
+    cut by it render the same image as an even cut."""
+    from bhr_amd import HipRenderer, scenes
+    from bhr_amd.multigpu import balanced_row_blocks, group_render, probe_row_costs, row_blocks
+    cam, fov, (w, h) = [6, 0, 0.5], 90, (256, 144)
+    sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
+    r = HipRenderer(w, h, sky, tex)
+    costs = r.row_costs(cam, fov)
+    steps = r.counters()["ray_steps"]
+    assert len(costs) == h // 8 and steps <= int(costs.sum()) <= 1.15 * steps     # ray-steps + 320 per shading pass
+    assert costs.max() > 1.05 * costs.min()                          # not flat: the ring rows take more steps, the shadow fewer
+    blank = HipRenderer(w, h, np.zeros((8, 16, 3), np.float32), np.zeros((32, 64, 4), np.float32))
+    np.testing.assert_array_equal(blank.row_costs(cam, fov), costs)  # the profile is texture independent
+    blank.close()
+    r.render_async(cam, fov)
+    with pytest.raises(AssertionError):                              # the last render carried no BHR_ROW_COSTS
+        from bhr_amd import _lib
+        import ctypes as C
+        _lib.check(_lib.load().bhr_get_row_costs(r._ctx, (C.c_uint64 * len(costs))(), len(costs)))
+    whole = r.render(cam, fov)
+    r.close()
+    per_row, band = probe_row_costs(w, h, cam, fov, scale=2)
+    blocks = balanced_row_blocks(h, 4, per_row, band)
+    assert blocks != row_blocks(h, 4) and all(r0 % 8 == 0 for r0, _ in blocks)
+    tiles = [HipRenderer(w, h, sky, tex, rows=b) for b in blocks]
+    img = group_render(tiles, cam, fov)
+    assert np.abs(img - whole).max() <= 1e-6
+    for t in tiles:
+        t.close()

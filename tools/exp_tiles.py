@@ -37,3 +37,11 @@ blocks = row_blocks(wl["height"], n)
 t = measure(blocks)
 print("uniform blocks:", [f"{a:.2f}" for a in t[:, 0]], f"efficiency {t[:, 0].mean() / t[:, 0].max():.3f}", flush=True)
 print("ray-steps share:", [f"{a / t[:, 2].sum():.3f}" for a in t[:, 2]])
+from bhr_amd.multigpu import balanced_row_blocks, probe_row_costs
+per_row, band = probe_row_costs(wl["width"], wl["height"], cam, fov, **kw)
+for fixed in (0.0, 0.1, 0.2):
+    blocks = balanced_row_blocks(wl["height"], n, per_row, band, fixed_cost_per_row=fixed * float(per_row.mean()))
+    t = measure(blocks)
+    print(f"balanced (fixed {fixed}):", [b[1] - b[0] for b in blocks], [f"{a:.2f}" for a in t[:, 0]],
+          f"efficiency {t[:, 0].mean() / t[:, 0].max():.3f}, max {t[:, 0].max():.2f} ms, "
+          f"vs one GPU {c['march_ms'] / (n * t[:, 0].max()):.3f}", flush=True)
