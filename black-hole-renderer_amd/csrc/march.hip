@@ -10,16 +10,19 @@
 // MFMA: the kernel is FP32 VALU + transcendental bound (DESIGN.md "Rooflines").
 //
 // Two schedules share the per-ray code:
-//  * tile (default): a wave owns one 8x8 pixel tile and loops until __ballot says
-//                no lane is alive (lane efficiency ~0.95 for the default view);
+//  * tile (default): a wave owns one 8x8 pixel tile; lanes leave the loop as their rays terminate (lane
+//                efficiency ~0.95 for the default view).  Tiles are launched nearest-to-the-hole first.
 //  * persistent (BHR_PERSISTENT): waves pull 8x8 tiles from a global queue; when the
 //                number of live lanes drops below a threshold the dead lanes write
 //                their pixel and are refilled from the next tile (wave-level
 //                __ballot / popcount compaction of the *work*, not of registers).
 //                Slower than the tile schedule for the BASELINE views.
+// Disk sources (template parameter SRC, own kernel instantiations): 0 texture / mip stack, 1 Disk V2 mid-plane
+// fields at each plane crossing, 2 Disk V2 finite-thickness emission-absorption integral (volume_segment).
+// Disk crossings are parked in per-lane LDS slots and shaded wave-wide (Pending, flush_one).
 //
-// Arithmetic differs from a strict f32 evaluation of the reference only in rounding: v_rsq/v_rcp/v_sqrt
-// instead of IEEE sqrt + divide inside the RK4 stages, FMA contraction, and the
+// The fast build's arithmetic differs from a strict f32 evaluation of the reference only in rounding:
+// v_rsq/v_rcp/v_sqrt instead of IEEE sqrt + divide inside the RK4 stages, FMA contraction, and the
 // re-use of |new_pos| as the next step's |pos| (same value in the reference).
 //
 // This file is compiled twice (csrc/Makefile):
@@ -31,11 +34,11 @@
 //                   render.py:2854-3006 (selected with bhr_config.math_mode = 1).
 #include <stdlib.h>
 
-#include "bhr_internal.h"
-
 #include <algorithm>
 #include <utility>
 #include <vector>
+
+#include "bhr_internal.h"
 #include "disk_v2_device.h"
 
 #ifndef BHR_MARCH_STRICT
@@ -379,7 +382,7 @@ __device__ __forceinline__ void shade_hit(const BhrMarchArgs &a, Shade &sh, floa
         lod = fminf(fmaxf(lod, 0.0f), 3.0f);
         lod_i = (int)fminf(fmaxf(lod, 0.0f), (float)(BHR_NUM_MIP_LEVELS - 1));
     }
-    // DV2 is a separate kernel instantiation: the binary64 model code (and its registers) never
+    // SRC == 1 is a separate kernel instantiation: the binary64 model code (and its registers) never
     // touches the texture kernels
     float4 rgba = SRC == 1 ? disk_v2_rgba(a, hit_x, hit_y)
                       : sample_disk_level(a.sc, hit_x, hit_y, a.r_inner, a.r_outer, a.t_offset, lod_i);
