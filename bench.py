@@ -77,7 +77,18 @@ def cpu_baseline(wl, sky, tex):
     t0 = time.perf_counter()
     ora.march(wl["cam_pos"], wl["fov"], skip_differentials=True, want_steps=False)
     t_skip = time.perf_counter() - t0
+    # one thread on a band of rows through the middle of the frame (SURVEY 8d asks for both figures)
+    h = wl["height"]
+    band = (h // 2 - h // 32, h // 2 + h // 32)
+    lib.oracle_set_num_threads(1)
+    t0 = time.perf_counter()
+    ora.march(wl["cam_pos"], wl["fov"], skip_differentials=False, want_steps=False, rows=band)
+    t_one = time.perf_counter() - t0
+    steps_one = ora.last_total_steps
+    lib.oracle_set_num_threads(cores)
     return {"value": steps / t_frame / 1e6, "unit": "Mray-steps/s", "cores": cores, "kind": "port",
+            "one_thread": {"value": steps_one / t_one / 1e6, "unit": "Mray-steps/s",
+                           "sample": f"rows {band[0]}..{band[1]} of the same frame, {steps_one} ray-steps in {t_one:.2f}s"},
             "sample": f"1 full {wl['width']}x{wl['height']} frame (march with differentials as the reference "
                       f"executes it + bloom), {steps} ray-steps in {t_frame:.2f}s",
             "fps": 1.0 / t_frame,
