@@ -26,8 +26,8 @@ namespace {
 constexpr int WPAD = 8;       // zero entries behind w[R] in the weight table (window overhang <= 6)
 constexpr int HB_PIX = 1024;  // pixels per H-pass block (256 threads x 4)
 constexpr int VB_COLS = 32;   // columns per V-pass block
-// output rows per V-pass block = 8 row-lanes x G groups x 4 rows.  Measured (v_groups): G = 2 (64 rows) up to
-// fhd, where the pass needs blocks more than it needs reuse (0.095 -> 0.079 ms); G = 4 at 4k; G = 8 (256 rows) at
+// output rows per V-pass block = 8 row-lanes x G groups x 4 rows.  Measured (v_groups): G = 1 (32 rows) up to
+// fhd, where the pass needs blocks more than it needs reuse (0.095 -> 0.073 ms); G = 4 at 4k; G = 8 (256 rows) at
 // 8k, where the 2R halo rows would otherwise outweigh the tile (2.0 -> 1.74 ms)
 
 __global__ void bloom_weights_kernel(float *wtab, int R, float sigma_scale) {
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
 
 // measured: 256-row tiles win at 8k (R = 153: 2.0 -> 1.74 ms) and lose at 4k (R = 76: one block fewer per CU)
 int v_groups(int R, int rows) {
-    if (const char *e = getenv("BHR_BLOOM_VG")) { int g = atoi(e); if (g == 2 || g == 4 || g == 8) return g; }
-    if (R < 64) return 2;   // fhd and below: 64-row tiles, twice the blocks -- the pass is short of waves, not of FMAs
+    if (const char *e = getenv("BHR_BLOOM_VG")) { int g = atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8) return g; }
+    if (R < 64) return 1;   // fhd and below: 32-row tiles -- the pass is short of waves (one round), not of FMAs
     return (R >= 128 && rows > 128) ? 8 : 4;
 }
 int v_stride(int R, int groups) {   // LDS column stride: >= tile rows, multiple of 4 with an odd quotient (bank spread)
@@ -242,7 +242,7 @@ int32_t bhr_bloom_prepare(bhr_ctx *ctx) {
     const int G = v_groups(R, ctx->rows);
     const size_t v_lds = (size_t)VB_COLS * v_stride(R, G) * sizeof(float);
     if (v_lds > 48 * 1024)
-        BHR_HIP(hipFuncSetAttribute(G == 8 ? (const void *)bloom_v_kernel<8> : G == 4 ? (const void *)bloom_v_kernel<4> : (const void *)bloom_v_kernel<2>,
+        BHR_HIP(hipFuncSetAttribute(G == 8 ? (const void *)bloom_v_kernel<8> : G == 4 ? (const void *)bloom_v_kernel<4> : G == 2 ? (const void *)bloom_v_kernel<2> : (const void *)bloom_v_kernel<1>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)v_lds));
     ctx->bloom_ready = 1;
     return BHR_OK;
@@ -273,6 +273,9 @@ int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom) {
                            ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom);
     else if (G == 4)
         hipLaunchKernelGGL(bloom_v_kernel<4>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
+                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom);
+    else if (G == 1)
+        hipLaunchKernelGGL(bloom_v_kernel<1>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
                            ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom);
     else
         hipLaunchKernelGGL(bloom_v_kernel<2>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,

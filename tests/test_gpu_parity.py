@@ -135,7 +135,7 @@ def test_bloom_isolated(oracle, hip_lib):
 
 @pytest.mark.parametrize("w,h", [(6500, 300), (3300, 200)])
 def test_bloom_wide_frame_tall_tiles(w, h, oracle, hip_lib):
-    """The V pass picks its tile height from R = int(0.02 W): 64 rows below R = 64 (every other test), 128 rows
+    """The V pass picks its tile height from R = int(0.02 W): 32 rows below R = 64 (every other test), 128 rows
     up to R = 127 (w = 3300), 256 rows above (w = 6500, the 8k case).  Wide strips with a synthetic disk layer
     through the standalone layer API, against the oracle's bloom; ragged in both directions."""
     from bhr_amd import HipRenderer, _lib
