@@ -632,6 +632,11 @@ static void volume_segment(v3 p0, v3 p1, v3 dir0, float tilt_rad, float t_offset
     }
 }
 
+/* Test hook: when set, every escaped ray also stores its escape direction here ((W, H, 3) doubles; captured
+ * rays store zeros).  Used by the convergence test against an independent geodesic integrator. */
+static double *g_escape_out;
+ORACLE_API void oracle_set_escape_out(double *buf) { g_escape_out = buf; }
+
 /* ---- camera uniforms as uploaded at render.py:3886-3892 ----------------- */
 typedef struct {
     f32 cam_pos[3], cam_right[3], cam_up[3], cam_forward[3];
@@ -853,6 +858,11 @@ ORACLE_API int64_t oracle_ray_march(const oracle_camera *cam, const oracle_march
             bg_color = v3_scale(1.0f - disk_alpha_total, bg_color);
 
             size_t o = ((size_t)i * height + j) * 3;
+            if (g_escape_out) {
+                g_escape_out[o + 0] = escaped ? (double)escape_dir.x : 0.0;
+                g_escape_out[o + 1] = escaped ? (double)escape_dir.y : 0.0;
+                g_escape_out[o + 2] = escaped ? (double)escape_dir.z : 0.0;
+            }
             image_out[o + 0] = bg_color.x; image_out[o + 1] = bg_color.y; image_out[o + 2] = bg_color.z;
             disk_out[o + 0] = clampf(accum_disk.x, 0.0f, 1.0f);
             disk_out[o + 1] = clampf(accum_disk.y, 0.0f, 1.0f);

@@ -79,6 +79,8 @@ def load(fast=False) -> C.CDLL:
     lib.oracle_dv2_eval.argtypes = [C.c_void_p, I32, D, D, D, I64, C.c_double, C.c_double, D]
     lib.oracle_set_volume.restype = None
     lib.oracle_set_volume.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I32]
+    lib.oracle_set_escape_out.restype = None
+    lib.oracle_set_escape_out.argtypes = [C.c_void_p]
     lib.oracle_num_threads.restype = I32
     lib.oracle_set_num_threads.argtypes = [I32]
     _libs[name] = lib
@@ -227,6 +229,16 @@ class OracleRenderer:
             steps.ctypes.data_as(C.POINTER(C.c_int32)) if want_steps else None, j_lo, j_hi)
         self.last_steps, self.last_total_steps = steps, int(total)
         return img, disk
+
+    def escape_directions(self, cam_pos, fov):
+        """(W, H, 3) float64 unit escape directions of the rays of one frame (zeros for captured rays)."""
+        buf = np.zeros((self.width, self.height, 3), dtype=np.float64)
+        self.lib.oracle_set_escape_out(buf.ctypes.data_as(C.c_void_p))
+        try:
+            self.march(cam_pos, fov, skip_differentials=True, want_steps=False)
+        finally:
+            self.lib.oracle_set_escape_out(None)
+        return buf
 
     def bloom(self, disk_layer):
         """_bloom_kernel as called at render.py:3914-3917. Returns (blur, mutated_disk_layer), (W,H,3)."""

@@ -234,3 +234,57 @@ def test_oracle_disk_v2_fields_match_reference_tables(oracle):
         m_h = np.abs(oracle.dv2_eval(ct, dv.F_HOTSPOT, rg, None, pg)).max()
         np.testing.assert_allclose(oracle.dv2_eval(ct, dv.F_TOTAL, rg, None, pg, norm_shear=m_s, norm_hotspot=m_h),
                                    gold[f"F_total_{seed}"], rtol=1e-12, atol=1e-13)
+
+
+# ---- the restated integrator against an independent one -------------------------------------------------
+def test_rk4_converges_to_the_geodesic_at_fourth_order(oracle):
+    """The escape directions of the binary64 build against SciPy's DOP853 on d2x/dl2 = -1.5 L^2 x / r^5 from the
+    same initial rays: the error falls ~16x per halving of step_size (RK4 with a step proportional to it) and is
+    below 1e-7 at step 0.025 -- the equation of motion, the RK4 tableau and the adaptive-step law are the
+    reference's (render.py:2518-2524, 2858-2882), the yardstick is not."""
+    from scipy.integrate import solve_ivp
+    w, h, fov, cam = 8, 6, 40.0, [9.0, 2.0, 3.0]
+    sky, tex = np.zeros((8, 16, 3), np.float32), np.zeros((8, 16, 4), np.float32)
+    r_far = 400.0
+
+    def directions(step):
+        o = oracle.OracleRenderer(w, h, sky, tex, step_size=step, r_max=r_far, r_disk_inner=2.0, r_disk_outer=3.0, fast="f64")
+        return o.escape_directions(cam, fov)
+
+    # the same pixel -> ray construction in binary64 (render.py:2811-2822)
+    p, right, up, fwd, pw, ph = oracle.build_camera(np.array(cam, dtype=np.float64), fov, w, h)
+    p32 = p.astype(np.float32).astype(np.float64)
+    r32, u32, f32 = (v.astype(np.float32).astype(np.float64) for v in (right, up, fwd))
+    pw, ph = float(np.float32(pw)), float(np.float32(ph))
+    tl = p32 + f32 - r32 * (pw * w / 2) + u32 * (ph * h / 2)
+    want = np.zeros((w, h, 3))
+    for i in range(w):
+        for j in range(h):
+            d0 = tl + (i + 0.5) * pw * r32 - (j + 0.5) * ph * u32 - p32
+            d0 /= np.linalg.norm(d0)
+            L2 = float(np.sum(np.cross(d0, p32) ** 2))
+
+            def rhs(_, y):
+                x = y[:3]
+                return np.concatenate([y[3:], -1.5 * L2 * x / np.dot(x, x) ** 2.5])
+
+            far = lambda _, y: np.dot(y[:3], y[:3]) - r_far ** 2
+            far.terminal, far.direction = True, 1
+            hole = lambda _, y: np.dot(y[:3], y[:3]) - 1.0          # r < rs: captured (render.py:2916)
+            hole.terminal, hole.direction = True, -1
+            sol = solve_ivp(rhs, (0.0, 5000.0), np.concatenate([p32, d0]), method="DOP853", rtol=1e-13, atol=1e-13,
+                            events=(far, hole))
+            assert sol.status == 1
+            if len(sol.t_events[0]):                                # escaped
+                want[i, j] = sol.y[3:, -1] / np.linalg.norm(sol.y[3:, -1])
+    errs = []
+    for step in (0.1, 0.05, 0.025):
+        got = directions(step)
+        esc = np.linalg.norm(want, axis=2) > 0
+        assert 12 <= esc.sum() < w * h                              # the view has both kinds of rays
+        np.testing.assert_array_equal(np.linalg.norm(got, axis=2) > 0, esc)     # same rays captured
+        assert (np.abs(np.linalg.norm(got[esc], axis=1) - 1) < 1e-6).all()
+        # at r ~ 400 the residual bending between the two stopping points is ~1e-9
+        errs.append(float(np.abs(got - want).max()))
+    assert errs[2] < 1e-7, errs
+    assert errs[0] / errs[1] > 8 and errs[1] / errs[2] > 8, errs
