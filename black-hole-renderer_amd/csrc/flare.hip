@@ -175,11 +175,17 @@ __global__ __launch_bounds__(256) void flare_apply_kernel(float *__restrict__ fi
 
     float fl[3] = {0.0f, 0.0f, 0.0f};
 
+    // Every shape is zero outside a disc, an annulus or a narrow wedge.  A conservative test on the squared
+    // distance (slack 1e-9, far above the rounding of the exact expressions) skips the square roots, atan2 and
+    // exp where the contribution is exactly 0 -- and adding 0 to the f32 accumulator would not change it.
+    const double SLACK = 1.0 + 1e-9;
     for (int g = 0; g < 8; ++g) {
         const double t = (g + 1) * 0.15;
         const double gx = src_x + (mid_x - src_x) * t, gy = src_y + (mid_y - src_y) * t;
         const double radius = (25 + g * 30) * scale;
-        const double dist = sqrt((x - gx) * (x - gx) + (y - gy) * (y - gy));
+        const double d2 = (x - gx) * (x - gx) + (y - gy) * (y - gy);
+        if (d2 > radius * radius * SLACK) continue;
+        const double dist = sqrt(d2);
         float alpha = 0.0f;
         if (dist < radius) {
             const double u = 1 - dist / radius;
@@ -191,7 +197,10 @@ __global__ __launch_bounds__(256) void flare_apply_kernel(float *__restrict__ fi
         const double t = 0.35 + k * 0.15;
         const double rx = src_x + (mid_x - src_x) * t, ry = src_y + (mid_y - src_y) * t;
         const double ring_r = (60 + k * 40) * scale, ring_w = (6 + k * 3) * scale;
-        const double dist = sqrt((x - rx) * (x - rx) + (y - ry) * (y - ry));
+        const double d2 = (x - rx) * (x - rx) + (y - ry) * (y - ry);
+        const double lo = fmax(ring_r - ring_w, 0.0), hi = ring_r + ring_w;
+        if (d2 > hi * hi * SLACK || d2 * SLACK < lo * lo) continue;
+        const double dist = sqrt(d2);
         const double c = clip01(1 - fabs(dist - ring_r) / ring_w);
         const double alpha = c * c * 0.5 * strength * (1 - k * 0.25);
         if (k == 0) add_tint(fl, alpha, 0.3, 0.4, 1.0);
@@ -202,28 +211,36 @@ __global__ __launch_bounds__(256) void flare_apply_kernel(float *__restrict__ fi
     {
         const double hx = src_x + (mid_x - src_x) * 0.5, hy = src_y + (mid_y - src_y) * 0.5;
         const double dx = x - hx, dy = y - hy;
-        const double angle = atan2(dy, dx);
-        const double dist = sqrt(dx * dx + dy * dy);
-        const double edge = fabs(np_mod(angle, PI / 3) - PI / 6);
-        const double facet = clip01(1 - edge / 0.2);
-        const double off = fabs(dist - 100 * scale);
-        const double c = clip01(1 - off / (15 * scale));
-        const double alpha = c * c * facet * 0.3 * strength;
-        add_tint(fl, alpha, 0.6, 0.7, 1.0);
+        const double d2 = dx * dx + dy * dy;
+        const double lo = 85 * scale, hi = 115 * scale;           // |dist - 100 scale| < 15 scale
+        if (!(d2 > hi * hi * SLACK || d2 * SLACK < lo * lo)) {
+            const double angle = atan2(dy, dx);
+            const double dist = sqrt(d2);
+            const double edge = fabs(np_mod(angle, PI / 3) - PI / 6);
+            const double facet = clip01(1 - edge / 0.2);
+            const double off = fabs(dist - 100 * scale);
+            const double c = clip01(1 - off / (15 * scale));
+            const double alpha = c * c * facet * 0.3 * strength;
+            add_tint(fl, alpha, 0.6, 0.7, 1.0);
+        }
     }
     {
         const double reach = fmin(w, h) * 0.4;
         const double dx = x - src_x, dy = y - src_y;
-        const double dist = sqrt(dx * dx + dy * dy);
-        const double angle = atan2(dy, dx);
-        const double a = exp(-dist / reach) * gain;     // falloff * streak_alpha, then * colour (4026)
-        const double axes[4] = {0.0, PI / 2, PI, 3 * PI / 2};
-        for (int s = 0; s < 4; ++s) {
-            const double delta = fabs(np_mod(angle - axes[s] + PI, 2 * PI) - PI);
-            const bool on = delta < 0.05;
-            fl[0] = (float)((double)fl[0] + (on ? a * 1.0 : 0.0));
-            fl[1] = (float)((double)fl[1] + (on ? a * 0.95 : 0.0));
-            fl[2] = (float)((double)fl[2] + (on ? a * 0.9 : 0.0));
+        // within 0.05 rad of one of the four axes  <=>  min(|dx|, |dy|) <= tan(0.05) max(|dx|, |dy|)
+        const double ax = fabs(dx), ay = fabs(dy);
+        if (fmin(ax, ay) <= 0.05005 * fmax(ax, ay)) {                 // tan(0.05) = 0.050042
+            const double dist = sqrt(dx * dx + dy * dy);
+            const double angle = atan2(dy, dx);
+            const double a = exp(-dist / reach) * gain;     // falloff * streak_alpha, then * colour (4026)
+            const double axes[4] = {0.0, PI / 2, PI, 3 * PI / 2};
+            for (int s = 0; s < 4; ++s) {
+                const double delta = fabs(np_mod(angle - axes[s] + PI, 2 * PI) - PI);
+                const bool on = delta < 0.05;
+                fl[0] = (float)((double)fl[0] + (on ? a * 1.0 : 0.0));
+                fl[1] = (float)((double)fl[1] + (on ? a * 0.95 : 0.0));
+                fl[2] = (float)((double)fl[2] + (on ? a * 0.9 : 0.0));
+            }
         }
     }
     float *q = fin + p * 3;
