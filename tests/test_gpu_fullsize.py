@@ -1,0 +1,95 @@
+"""Parity at the BASELINE.json frame sizes (fhd, 4k, 8k), where the oracle cannot render a whole frame in test
+time: bands of rows against the oracle, and size-independent properties -- determinism, mirror symmetry of a
+mirror-symmetric scene, linearity of the disk layer in the texture colour, row block == full frame."""
+import numpy as np
+import pytest
+
+from bhr_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+@pytest.mark.parametrize("name,w,h,kw,bands", [
+    ("fhd", 1920, 1080, dict(step_size=0.1, disk_tilt=0.0, anti_alias="disabled"), [(96, 104), (532, 548), (1000, 1008)]),
+    ("4k", 3840, 2160, dict(step_size=0.1, disk_tilt=25.0, anti_alias="lod_radius"), [(1072, 1080), (400, 404)]),
+    ("8k", 7680, 4320, dict(step_size=0.05, disk_tilt=0.0, anti_alias="disabled"), [(2158, 2162)]),
+])
+def test_row_bands_match_oracle_at_baseline_sizes(name, w, h, kw, bands, oracle, hip_lib):
+    from bhr_amd import HipRenderer, _lib
+    sky, tex = scenes.analytic_skybox(), scenes.noisy_disk(256, 1024)
+    cam, fov = [6, 0, 0.5], 90
+    hip = HipRenderer(w, h, sky, tex, **kw)
+    hip.render_async(cam, fov, skip_bloom=True)
+    bg, disk = hip.read_layer(_lib.LAYER_BG), hip.read_layer(_lib.LAYER_DISK)
+    ora = oracle.OracleRenderer(w, h, sky, tex, fast=False, **kw)
+    for (r0, r1) in bands:
+        rbg, rdisk = ora.march(cam, fov, rows=(r0, r1), want_steps=False)
+        rbg, rdisk = rbg.transpose(1, 0, 2)[r0:r1], rdisk.transpose(1, 0, 2)[r0:r1]
+        assert _rmse(bg[r0:r1], rbg) <= 5e-6 and _rmse(disk[r0:r1], rdisk) <= 5e-6, (name, r0)
+        assert np.abs(bg[r0:r1] - rbg).max() <= 2e-4 and np.abs(disk[r0:r1] - rdisk).max() <= 2e-4
+    hip.close()
+
+
+def test_fhd_determinism_and_row_block(hip_lib):
+    from bhr_amd import HipRenderer, _lib
+    sky, tex = scenes.analytic_skybox(), scenes.noisy_disk(256, 1024)
+    cam, fov = [6, 0, 0.5], 90
+    r = HipRenderer(1920, 1080, sky, tex)
+    a = r.render(cam, fov)
+    b = r.render(cam, fov)
+    np.testing.assert_array_equal(a, b)                               # bit-identical from run to run
+    r.render_async(cam, fov, skip_bloom=True)
+    disk = r.read_layer(_lib.LAYER_DISK)
+    r.close()
+    blk = HipRenderer(1920, 1080, sky, tex, rows=(536, 808))
+    blk.render_async(cam, fov, skip_bloom=True)
+    np.testing.assert_array_equal(blk.read_layer(_lib.LAYER_DISK), disk[536:808])
+    blk.close()
+
+
+def test_fhd_mirror_symmetry_and_linearity(hip_lib):
+    """Camera in the x-z plane and a sky that is even in phi: with a transparent disk the frame is its own mirror
+    image about the vertical centre line, up to the rounding of mirrored arithmetic (amplified next to the photon
+    ring).  The disk itself is NOT mirror symmetric -- it rotates, the approaching side is Doppler-boosted -- but
+    its layer is linear in the texture colour while nothing clamps."""
+    from bhr_amd import HipRenderer, _lib
+    n_r, n_phi = 128, 512
+    phi = (np.arange(n_phi) + 0.5) / n_phi * 2 * np.pi
+    rr = (np.arange(n_r) + 0.5) / n_r
+    tex = np.zeros((n_r, n_phi, 4), np.float32)
+    tex[..., 0] = 0.05 + 0.04 * np.cos(3 * phi)[None, :] * rr[:, None]
+    tex[..., 1] = 0.04 + 0.03 * np.cos(phi)[None, :]
+    tex[..., 2] = 0.03
+    tex[..., 3] = 0.5 + 0.3 * np.cos(2 * phi)[None, :] * (1 - rr)[:, None]
+    sh, sw = 256, 512
+    v = (np.arange(sh) + 0.5) / sh
+    u = np.arange(sw) / sw * 2 * np.pi          # _sample_skybox puts texel k at phi = 2 pi k / W (render.py:2541-2566)
+    sky = np.zeros((sh, sw, 3), np.float32)
+    sky[..., 0] = 0.3 + 0.2 * np.cos(u)[None, :] * np.sin(np.pi * v)[:, None]
+    sky[..., 1] = 0.2 + 0.1 * np.cos(2 * u)[None, :]
+    sky[..., 2] = 0.5 * v[:, None]
+    # cos(k phi_k) with phi_k = 2 pi k / W: texel k equals texel (W - k) mod W, the sampler's own mirror
+    r = HipRenderer(1920, 1080, sky, tex, disk_tilt=0.0)
+    clear = tex.copy()
+    clear[..., 3] = 0.0
+    r.update_disk_texture(clear)
+    r.render_async([6, 0, 0.5], 90, skip_bloom=True)
+    bg = r.read_layer(_lib.LAYER_BG)
+    assert bg.max() > 0.3 and r.read_layer(_lib.LAYER_DISK).max() == 0.0
+    assert _rmse(bg, bg[:, ::-1]) <= 1e-4 and np.median(np.abs(bg - bg[:, ::-1])) <= 2e-6
+    r.update_disk_texture(tex)
+    r.render_async([6, 0, 0.5], 90, skip_bloom=True)
+    disk = r.read_layer(_lib.LAYER_DISK)
+    assert _rmse(disk, disk[:, ::-1]) > 1e-3                           # Doppler beaming: brighter on the approaching side
+    dim = tex.copy()
+    dim[..., :3] *= 0.25
+    r.update_disk_texture(dim)
+    r.render_async([6, 0, 0.5], 90, skip_bloom=True)
+    disk_dim = r.read_layer(_lib.LAYER_DISK)
+    assert 0.05 < disk.max() < 0.999                                   # visible, nothing clipped
+    np.testing.assert_allclose(disk_dim, 0.25 * disk, rtol=2e-6, atol=1e-8)
+    r.close()
