@@ -93,3 +93,36 @@ def test_fhd_mirror_symmetry_and_linearity(hip_lib):
     assert 0.05 < disk.max() < 0.999                                   # visible, nothing clipped
     np.testing.assert_allclose(disk_dim, 0.25 * disk, rtol=2e-6, atol=1e-8)
     r.close()
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160), (7680, 4320)])
+def test_bloom_properties_at_baseline_sizes(w, h, hip_lib):
+    """The bloom at the three BASELINE widths (radius 38 / 76 / 153: the three V-pass tile heights), through
+    properties that need no oracle: a constant layer is a fixed point (per-channel renormalisation over the
+    in-bounds taps, render.py:3068-3074, edges included), the operator is linear, and it commutes with the
+    left-right flip."""
+    from bhr_amd import HipRenderer, _lib
+    r = HipRenderer(w, h, np.zeros((16, 32, 3), np.float32), np.zeros((32, 64, 4), np.float32))
+    zero = np.zeros((h, w, 3), np.float32)
+    r.write_layer(_lib.LAYER_BG, zero)
+
+    def bloom(x):
+        r.write_layer(_lib.LAYER_DISK, x)
+        r.bloom_only()
+        return r.read_layer(_lib.LAYER_BLUR)
+
+    const = np.empty((h, w, 3), np.float32)
+    const[...] = np.array([0.25, 0.5, 0.125], np.float32)
+    np.testing.assert_allclose(bloom(const), const, rtol=0, atol=2e-6)
+    rng = np.random.default_rng(w)
+    x = np.zeros((h, w, 3), np.float32)
+    ys, xs = rng.integers(0, h, 3000), rng.integers(0, w, 3000)
+    x[ys, xs] = rng.random((3000, 3), dtype=np.float32)
+    x[h // 3:h // 3 + 40, w // 5:w // 5 + 300] = 0.6
+    bx = bloom(x)
+    assert bx.max() > 0.05 and np.isfinite(bx).all()
+    np.testing.assert_allclose(bloom(0.5 * x), 0.5 * bx, rtol=1e-6, atol=1e-9)          # halving is exact in f32
+    np.testing.assert_allclose(bloom(np.ascontiguousarray(x[:, ::-1])), bx[:, ::-1], rtol=2e-5, atol=2e-7)
+    # mass moves, it is not created: every output is a convex combination of inputs
+    assert bx.max() <= x.max() + 1e-6 and bx.min() >= 0.0
+    r.close()
