@@ -62,6 +62,41 @@ def test_background_matches_oracle(hip_lib, oracle, t):
     r.close()
 
 
+def test_background_and_compose_at_the_fhd_texture_size(hip_lib, oracle):
+    """The fhd frame's own texture (416 x 2912, compute_disk_texture_resolution): background planes against the
+    oracle with the same robust statistics as above, then the compose kernel + mip chain against the oracle's
+    compose of the SAME planes (tolerances of tests/unit/test_gpu_texture_compose.py)."""
+    from bhr_amd import HipRenderer
+    from bhr_amd.textures import compute_disk_texture_resolution, compute_edge_alpha
+    n_phi, n_r = compute_disk_texture_resolution(1920, 1080, [6, 0, 0.5], 90, 2.0, 15.0)
+    assert (n_r, n_phi) == (416, 2912)
+    r = HipRenderer(64, 36, scenes.analytic_skybox(32, 64), np.zeros((n_r, n_phi, 4), dtype=np.float32),
+                    r_disk_inner=2.0, r_disk_outer=15.0)
+    r.init_background_layer(n_r, n_phi, seed=42)
+    r.generate_background(5.0)
+    got = r.read_comp()
+    want = oracle.generate_background(n_r, n_phi, r._bg_az_freq, r._bg_az_shear, 2.0, 15.0, 5.0)
+    for idx in (0, 3, 4, 11, 12):
+        d = np.abs(got[idx] - want[idx])
+        assert np.mean(d) < 2e-5 and np.quantile(d, 0.999) < 2e-3, (idx, np.mean(d))
+    assert got[0].min() >= 0 and got[0].max() <= 0.35 and got[3].max() <= 1 and got[12].min() >= 0.1 - 1e-6
+    # compose the device's planes on both sides
+    r.recompute_interactive_stats()
+    r.compose_interactive_texture()
+    tex = r.disk_texture_field.to_numpy()
+    stats = r._param_stats_field.to_numpy()
+    row_stats = r._param_row_stats_field.to_numpy()
+    ref = oracle.compose_disk_texture(got, r._omega_rows_field.to_numpy(), r._edge_field.to_numpy(), stats, row_stats,
+                                      t_offset=0.0)
+    assert np.abs(tex - ref).max() < 1e-4
+    assert tex[..., :3].std() > 0.01 and tex[..., 3].max() > 0.01 and np.isfinite(tex).all()
+    mips = oracle.build_mips_padded(tex)
+    for level in range(1, r.num_mip_levels):
+        mh, mw = n_r >> level, n_phi >> level
+        assert np.abs(r.read_mip_level(level) - mips[level, :mh, :mw]).max() < 1e-3
+    r.close()
+
+
 def test_generate_background_requires_init(hip):
     with pytest.raises(AssertionError):
         hip.generate_background(0.0)                           # "Must call init_background_layer() first"
