@@ -426,8 +426,8 @@ int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         BHR_TRY(bhr_launch_flare_sums(ctx));
         BHR_TRY(bhr_launch_flare_apply(ctx, nullptr));
     }
-    BHR_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     BHR_HIP(hipEventRecord(ctx->ring_ev[slot * 3 + 2], ctx->stream));
+    ctx->last_slot = slot;
     ctx->ring_head += 1;
     ctx->last_flags = (int32_t)flags;
     ctx->timing_valid = 1;
@@ -506,9 +506,11 @@ int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {
         unsigned long long steps = 0;
         BHR_TRY(fold_cells(ctx, ctx->last_steps_ptr ? ctx->last_steps_ptr : ctx->d_ray_steps, 1, &steps));
         ctx->counters.ray_steps = steps;
-        ctx->counters.march_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
-        ctx->counters.bloom_ms = ev_ms(ctx->ev[1], ctx->ev[2]);
-        ctx->counters.frame_ms = ev_ms(ctx->ev[0], ctx->ev[2]);
+        // the last launch's three events: its ring slot's (bhr_render) or the context's scalar ones (group render)
+        const hipEvent_t *e = ctx->last_slot >= 0 ? ctx->ring_ev + ctx->last_slot * 3 : ctx->ev;
+        ctx->counters.march_ms = ev_ms(e[0], e[1]);
+        ctx->counters.bloom_ms = ev_ms(e[1], e[2]);
+        ctx->counters.frame_ms = ev_ms(e[0], e[2]);
     }
     {
         const int64_t n = ctx->ring_head < BHR_TIMING_RING ? ctx->ring_head : BHR_TIMING_RING;
@@ -603,6 +605,7 @@ int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint3
     for (int k = 0; k < n; ++k) {
         BHR_TRY(use_device(ctxs[k]));
         ctxs[k]->cur_slot = -1;
+        ctxs[k]->last_slot = -1;
         BHR_TRY(bhr_launch_march(ctxs[k], cam, flags));
         if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctxs[k]));
         BHR_HIP(hipEventRecord(ctxs[k]->ev[3], ctxs[k]->stream));

@@ -85,6 +85,7 @@ struct bhr_ctx {
     int64_t ring_head;                  // frames recorded since reset
     unsigned long long *last_steps_ptr; // counter the last march accumulated into
     int32_t cur_slot;                   // ring slot of the bhr_render in flight (-1: untimed launch)
+    int32_t last_slot;                  // ring slot of the last completed bhr_render, -1 after a group render
 
     // scene
     float *d_skybox;

@@ -1191,8 +1191,8 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
 
     BHR_HIP(hipMemsetAsync(a.ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream));
     if (flags & BHR_PERSISTENT) BHR_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned int), ctx->stream));
-    BHR_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (slot >= 0) BHR_HIP(hipEventRecord(ctx->ring_ev[slot * 3 + 0], ctx->stream));
+    // timed launches (bhr_render) use their ring slot's events, the others the context's scalar ones
+    BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 0] : ctx->ev[0], ctx->stream));
     if (!(flags & BHR_PERSISTENT) || a.dv2 || a.row_steps) {   // the persistent schedule has no Disk V2 / row-cost variant
         // waves per block: a block keeps its CU slot until its slowest wave has finished, so small
         // blocks shorten the tail; BHR_TILE_BLOCK overrides for experiments
@@ -1227,8 +1227,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
             hipLaunchKernelGGL(march_persistent_kernel<false>, grid, block, 0, ctx->stream, a, refill_below);
     }
     BHR_HIP(hipGetLastError());
-    BHR_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-    if (slot >= 0) BHR_HIP(hipEventRecord(ctx->ring_ev[slot * 3 + 1], ctx->stream));
+    BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 1] : ctx->ev[1], ctx->stream));
     ctx->last_steps_ptr = a.ray_steps;
     ctx->counters.rays = (uint64_t)c.width * ctx->rows;
     return BHR_OK;
