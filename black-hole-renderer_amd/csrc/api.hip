@@ -198,7 +198,8 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     if ((rc = dev_alloc(&ctx->d_steps_ring, (size_t)BHR_TIMING_RING * BHR_STEP_CELL))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_steps_fold, BHR_TIMING_RING))) return bail(rc);
     if (hipMemsetAsync(ctx->d_hblur, 0, 3 * (rows + 2 * R) * W * sizeof(float), ctx->stream) != hipSuccess ||
-        hipMemsetAsync(ctx->d_ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream) != hipSuccess)
+        hipMemsetAsync(ctx->d_ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(ctx->d_steps_ring, 0, sizeof(unsigned long long) * BHR_TIMING_RING * BHR_STEP_CELL, ctx->stream) != hipSuccess)
         return bail(bhr_fail(BHR_ERR_HIP, "hipMemsetAsync failed"));
     int32_t v = 0, l = 0;
     if (cfg->math_mode != BHR_MATH_FAST && cfg->math_mode != BHR_MATH_STRICT)
@@ -418,7 +419,10 @@ int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     BHR_TRY(bhr_launch_march(ctx, cam, flags));  // records ev[0]/ev[1] and the ring's march events
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctx));
-    BHR_TRY(bhr_launch_bloom_v(ctx, with_bloom));
+    ctx->v_zero_cell = ctx->d_steps_ring + (size_t)((slot + 1) % BHR_TIMING_RING) * BHR_STEP_CELL;
+    const int32_t rc_v = bhr_launch_bloom_v(ctx, with_bloom);
+    ctx->v_zero_cell = nullptr;
+    BHR_TRY(rc_v);
     if (flags & BHR_LENS_FLARE) {
         if (ctx->rows != ctx->cfg.height)
             return bhr_fail(BHR_ERR_INVALID, "bhr_render: the lens flare needs whole-frame sums; use bhr_group_render for row blocks");
@@ -563,6 +567,7 @@ int32_t bhr_get_row_costs(bhr_ctx *ctx, uint64_t *out, int32_t n) {
 int32_t bhr_timing_reset(bhr_ctx *ctx) {
     if (!ctx) return bhr_fail(BHR_ERR_INVALID, "null ctx");
     BHR_TRY(use_device(ctx));
+    BHR_HIP(hipMemsetAsync(ctx->d_steps_ring, 0, sizeof(unsigned long long) * BHR_TIMING_RING * BHR_STEP_CELL, ctx->stream));
     BHR_HIP(hipStreamSynchronize(ctx->stream));
     ctx->ring_head = 0;
     return BHR_OK;

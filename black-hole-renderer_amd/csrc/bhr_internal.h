@@ -82,6 +82,7 @@ struct bhr_ctx {
     hipEvent_t ring_ev[BHR_TIMING_RING * 3];
     unsigned long long *d_steps_ring;   // one ray-step counter cell (BHR_STEP_CELL words) per ring slot
     unsigned long long *d_steps_fold;   // folded cells (BHR_TIMING_RING words)
+    unsigned long long *v_zero_cell;    // counter cell the next bloom V launch clears (next ring slot), or null
     int64_t ring_head;                  // frames recorded since reset
     unsigned long long *last_steps_ptr; // counter the last march accumulated into
     int32_t cur_slot;                   // ring slot of the bhr_render in flight (-1: untimed launch)

@@ -136,7 +136,12 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
                                                       const float *__restrict__ disk, float *__restrict__ blur_out,
                                                       float *__restrict__ final_out, const float *__restrict__ wext,
                                                       const float *__restrict__ wsum_v, int W, int H, int row0,
-                                                      int rows, int R, int S, int with_bloom) {
+                                                      int rows, int R, int S, int with_bloom,
+                                                      unsigned long long *__restrict__ zero_cell) {
+    // housekeeping folded into the frame's last kernel: clear the ray-step counter cell of the NEXT timed frame,
+    // which saves a fill dispatch (and its barrier) in front of every march
+    if (zero_cell && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < BHR_STEP_LANES)
+        zero_cell[(size_t)threadIdx.x * BHR_STEP_STRIDE] = 0ull;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [VB_COLS][S], column-major tile
     const int R4 = (R + 3) & ~3;
     const int col = threadIdx.x & (VB_COLS - 1);
@@ -270,16 +275,16 @@ int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom) {
     size_t lds = with_bloom ? (size_t)VB_COLS * S * sizeof(float) : 0;
     if (G == 8)
         hipLaunchKernelGGL(bloom_v_kernel<8>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
-                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom);
+                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom, ctx->v_zero_cell);
     else if (G == 4)
         hipLaunchKernelGGL(bloom_v_kernel<4>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
-                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom);
+                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom, ctx->v_zero_cell);
     else if (G == 1)
         hipLaunchKernelGGL(bloom_v_kernel<1>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
-                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom);
+                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom, ctx->v_zero_cell);
     else
         hipLaunchKernelGGL(bloom_v_kernel<2>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
-                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom);
+                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom, ctx->v_zero_cell);
     BHR_HIP(hipGetLastError());
     return BHR_OK;
 }

@@ -1189,7 +1189,8 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     // the CLI path) but never reads them (render.py:2957-2959) => skipping them is pixel-identical.
     const bool want_diff = c.anti_alias != 0 && !(flags & BHR_SKIP_DIFFERENTIALS);
 
-    BHR_HIP(hipMemsetAsync(a.ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream));
+    // ring cells are cleared ahead of time (at reset, then by the previous frame's last kernel)
+    if (slot < 0) BHR_HIP(hipMemsetAsync(a.ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream));
     if (flags & BHR_PERSISTENT) BHR_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned int), ctx->stream));
     // timed launches (bhr_render) use their ring slot's events, the others the context's scalar ones
     BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 0] : ctx->ev[0], ctx->stream));
