@@ -171,6 +171,8 @@ int32_t bhr_fail(int32_t code, const char *fmt, ...);
 int32_t bhr_launch_march(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);         // dispatches on math_mode
 int32_t bhr_launch_march_strict(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);  // march_strict.o
 int32_t bhr_march_resources_strict(int32_t *vgprs, int32_t *lds, int32_t diff);
+int32_t bhr_launch_march_strict_ilp(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);   // march_strict_ilp.o
+int32_t bhr_march_resources_strict_ilp(int32_t *vgprs, int32_t *lds, int32_t diff);
 int32_t bhr_selftest_strict(bhr_ctx *ctx, unsigned long long *d_out4);
 int32_t bhr_bloom_prepare(bhr_ctx *ctx);
 int32_t bhr_launch_bloom_h(bhr_ctx *ctx);

@@ -13,7 +13,7 @@ for f in api output flare lifecycle api_disk_v2 disk_v2 bloom texture; do
       -fno-omit-frame-pointer -Wno-option-ignored -c $f.hip -o $OUT/$f.o &
 done
 wait
-cp ../lib/obj/march.o ../lib/obj/march_strict.o $OUT/      # device-heavy objects: no host code worth instrumenting
+cp ../lib/obj/march.o ../lib/obj/march_strict.o ../lib/obj/march_strict_ilp.o $OUT/      # device-heavy objects: no host code worth instrumenting
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -o $OUT/libbhr_hip.so $OUT/*.o -lz -lpthread
 ASAN=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 cd $ROOT
