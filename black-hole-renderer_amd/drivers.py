@@ -35,7 +35,7 @@ def save_image(image: np.ndarray, path: str) -> None:
         png_write(path, quantize(image))
     else:
         from PIL import Image
-        Image.fromarray(quantize(image), "RGB").save(path)
+        Image.fromarray(quantize(image)).save(path)
     print(f"Saved: {path}")
 
 

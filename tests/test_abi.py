@@ -12,7 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     inc = os.path.join(ROOT, "include")
-    text = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
+    text = ""
+    for f in sorted(os.listdir(inc)):
+        if f.endswith(".h"):
+            with open(os.path.join(inc, f)) as fh:
+                text += fh.read()
     return sorted(set(re.findall(r"BHR_API\s+[\w\s\*]+?\b(bhr_[a-z0-9_]+)\s*\(", text)))
 
 

@@ -43,7 +43,7 @@ def test_png_band_splice_large_and_compresses():
     data = png_encode(img, level=6, threads=8)
     np.testing.assert_array_equal(_decode(data), img)
     ref = io.BytesIO()
-    Image.fromarray(img, "RGB").save(ref, format="PNG")
+    Image.fromarray(img).save(ref, format="PNG")
     assert len(data) < 1.25 * len(ref.getvalue())
 
 

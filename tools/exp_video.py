@@ -22,7 +22,7 @@ r.render_async([6, 0, 0.5], 90)
 u8 = r.read_final_u8()
 t0 = time.perf_counter()
 with ThreadPoolExecutor(2) as pool:
-    list(pool.map(lambda k: Image.fromarray(u8, "RGB").save(os.path.join(tmp, f"pil{k}.png")), range(16)))
+    list(pool.map(lambda k: Image.fromarray(u8).save(os.path.join(tmp, f"pil{k}.png")), range(16)))
 dt = time.perf_counter() - t0
 print(f"PIL 2 threads: {16 / dt:.1f} fps ({os.path.getsize(os.path.join(tmp, 'pil0.png')) / 1e6:.2f} MB/frame)")
 from bhr_amd.output import png_encode
