@@ -80,9 +80,11 @@ def test_product_does_not_import_the_oracle():
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
-                text = open(os.path.join(dirpath, f), errors="replace").read()
+                with open(os.path.join(dirpath, f), errors="replace") as fh:
+                    text = fh.read()
                 assert "oracle" not in text.lower(), f"{f} mentions the oracle"
     for f in ("render.py",):
         p = os.path.join(ROOT, f)
         if os.path.isfile(p):
-            assert "oracle" not in open(p).read().lower()
+            with open(p) as fh:
+                assert "oracle" not in fh.read().lower()
