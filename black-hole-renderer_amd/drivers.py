@@ -85,7 +85,9 @@ def make_renderer(width, height, cam_pos, fov, step_size=0.1, skybox_path=None, 
                   aa_strength=1.0, disk_rotation_speed=0.1, device_index=0, rows=None):
     """Renderer with a placeholder (or file) disk texture, as the reference's entry points build it
     (render.py:4044-4064, 4627-4644).  Returns (renderer, use_lifecycle, n_r, n_phi)."""
-    skybox, tex_h, tex_w = load_or_generate_skybox(skybox_path, tex_w, tex_h, n_stars)
+    # procedural sky: the random part on the host, the closed-form Milky-Way glow on the device (skyglow.hip)
+    skybox, tex_h, tex_w = load_or_generate_skybox(skybox_path, tex_w, tex_h, n_stars, glow=False)
+    procedural_sky = load_or_generate_skybox.procedural
     disk_tex = load_disk_texture(disk_texture_path)
     use_lifecycle = disk_tex is None
     if use_lifecycle:
@@ -97,6 +99,8 @@ def make_renderer(width, height, cam_pos, fov, step_size=0.1, skybox_path=None, 
                            r_disk_inner=r_disk_inner, r_disk_outer=r_disk_outer, disk_tilt=disk_tilt,
                            lens_flare=lens_flare, anti_alias=anti_alias, aa_strength=aa_strength,
                            disk_rotation_speed=disk_rotation_speed, device_index=device_index, rows=rows)
+    if procedural_sky:
+        renderer.add_skybox_glow()
     return renderer, use_lifecycle, n_r, n_phi
 
 

@@ -114,6 +114,16 @@ class HipRenderer:
         return self.row1 - self.row0
 
     # ------------------------------------------------------------------ textures
+    def add_skybox_glow(self) -> None:
+        """Milky-Way glow + clip of generate_skybox (render.py:296-341) on the device, in place; the sky given to the
+        constructor must be generate_skybox(..., glow=False)."""
+        _lib.check(self._lib.bhr_skybox_add_glow(self._ctx))
+
+    def read_skybox(self) -> np.ndarray:
+        out = np.empty((self.tex_h, self.tex_w, 3), dtype=np.float32)
+        _lib.check(self._lib.bhr_get_skybox(self._ctx, _lib.fptr(out)))
+        return out
+
     def update_disk_texture(self, new_disk_tex: np.ndarray) -> None:
         """Replace the disk texture and rebuild its mip chain (render.py:2292-2312)."""
         dtex_h, dtex_w = new_disk_tex.shape[:2]

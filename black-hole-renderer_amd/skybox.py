@@ -91,8 +91,10 @@ def _star_masses_and_magnitudes(rng, n_stars):
     return mass[pick], app_mag[pick]
 
 
-def generate_skybox(tex_w: int = 2048, tex_h: int = 1024, seed: int = 42, n_stars: int = 6000) -> np.ndarray:
-    """(tex_h, tex_w, 3) float32 in [0, 1], seamless in u."""
+def generate_skybox(tex_w: int = 2048, tex_h: int = 1024, seed: int = 42, n_stars: int = 6000, glow: bool = True) -> np.ndarray:
+    """(tex_h, tex_w, 3) float32 in [0, 1], seamless in u.  ``glow=False`` stops before the Milky-Way glow and
+    the final clip: the order-sensitive random part (nebula + star splats), to which the device adds the glow
+    (HipRenderer.add_skybox_glow, csrc/skyglow.hip)."""
     from PIL import Image
 
     rng = np.random.default_rng(seed)
@@ -131,6 +133,9 @@ def generate_skybox(tex_w: int = 2048, tex_h: int = 1024, seed: int = 42, n_star
     contrib = np.repeat(colors, n_patch, axis=0)[ok.ravel()] * vals[ok][:, None]
     np.add.at(sky, (py[ok], px[ok]), contrib)
 
+    if not glow:
+        return sky
+
     # Milky-Way glow in galactic coordinates
     v_grid = np.linspace(0, np.pi, tex_h)
     u_grid = np.linspace(0, 2 * np.pi, tex_w)
@@ -152,9 +157,11 @@ def generate_skybox(tex_w: int = 2048, tex_h: int = 1024, seed: int = 42, n_star
 
 
 def load_or_generate_skybox(skybox_path: Optional[str], tex_w: int = 2048, tex_h: int = 1024,
-                            n_stars: int = 6000) -> Tuple[np.ndarray, int, int]:
+                            n_stars: int = 6000, glow: bool = True) -> Tuple[np.ndarray, int, int]:
     """Image file if it exists, otherwise the procedural sky (render.py:344-368).
-    Returns (texture, tex_h, tex_w)."""
+    Returns (texture, tex_h, tex_w).  ``glow=False``: see generate_skybox; an image file is returned as it is
+    and ``load_or_generate_skybox.procedural`` tells the caller which of the two it got."""
+    load_or_generate_skybox.procedural = not (skybox_path and os.path.isfile(skybox_path))
     if skybox_path and os.path.isfile(skybox_path):
         from PIL import Image
         print(f"Loading skybox: {skybox_path}")
@@ -165,4 +172,4 @@ def load_or_generate_skybox(skybox_path: Optional[str], tex_w: int = 2048, tex_h
         print(f"Texture not found: {skybox_path}, generating procedural skybox...")
     else:
         print("Generating procedural skybox...")
-    return generate_skybox(tex_w=tex_w, tex_h=tex_h, n_stars=n_stars), tex_h, tex_w
+    return generate_skybox(tex_w=tex_w, tex_h=tex_h, n_stars=n_stars, glow=glow), tex_h, tex_w

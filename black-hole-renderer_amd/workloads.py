@@ -17,11 +17,13 @@ def make_scene(wl: dict, device_index: int = 0, n_stars: int = 6000, math=None):
     W, H = wl["width"], wl["height"]
     r_in, r_out = 2.0, 15.0
     n_phi, n_r = compute_disk_texture_resolution(W, H, wl["cam_pos"], wl["fov"], r_in, r_out)
-    sky = generate_skybox(2048, 1024, seed=42, n_stars=n_stars)
+    sky = generate_skybox(2048, 1024, seed=42, n_stars=n_stars, glow=False)     # + the glow on the device, below
     placeholder = np.zeros((n_r, n_phi, 4), dtype=np.float32)
     r = HipRenderer(W, H, sky, placeholder, step_size=wl["step_size"], r_max=10.0, r_disk_inner=r_in,
                     r_disk_outer=r_out, disk_tilt=wl["disk_tilt"], anti_alias=wl["anti_alias"],
                     device_index=device_index, **({} if math is None else {"math": math}))
+    r.add_skybox_glow()
+    sky = r.read_skybox()
     factories = init_lifecycle_system(r, n_r, n_phi, seed=42)
     advance_lifecycle_frame(r, factories, t=0.0, dt=0.0, recompute_stats=True)
     tex = r.disk_texture_field.to_numpy()

@@ -133,6 +133,11 @@ BHR_API int32_t bhr_sync(bhr_ctx *ctx);
 /* ---- scene data ----------------------------------------------------------- */
 /* texture_field.from_numpy(skybox): (tex_h, tex_w, 3) f32   render.py:2232-2233 */
 BHR_API int32_t bhr_set_skybox(bhr_ctx *ctx, const float *rgb, int32_t tex_h, int32_t tex_w);
+/* The Milky-Way glow of generate_skybox (render.py:296-341) added to the uploaded sky on the device, followed by
+ * its clip(0, 1): upload the sky WITHOUT the glow (nebula + stars, the order-sensitive host part), call this once.
+ * bhr_get_skybox reads the texture back ((tex_h, tex_w, 3) f32).  Asynchronous / synchronous. */
+BHR_API int32_t bhr_skybox_add_glow(bhr_ctx *ctx);
+BHR_API int32_t bhr_get_skybox(bhr_ctx *ctx, float *out);
 /* disk_texture_field.from_numpy + generate_disk_mipmaps(levels=4) + padded
  * upload (render.py:2235-2251, update_disk_texture 2292-2312).  (n_r, n_phi, 4)
  * f32.  The first call fixes (n_r, n_phi); later calls must match

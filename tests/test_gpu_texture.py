@@ -174,3 +174,22 @@ def test_lifecycle_texture_end_to_end(hip_lib, oracle):
     img = r.render([6, 0, 0.5], 60)
     assert img.shape == (180, 320, 3) and img.max() > 0.01 and np.isfinite(img).all()   # test_lifecycle_perf.py:191-201
     r.close()
+
+
+@pytest.mark.parametrize("tex_w,tex_h,n_stars", [(256, 128, 300), (2048, 1024, 6000)])
+def test_skybox_glow_on_the_device(hip_lib, tex_w, tex_h, n_stars):
+    """Host random part + device Milky-Way glow == the host generator (itself pinned to the reference by
+    tests/golden: full 64x32 texture and the SHA-256 of the 2048x1024 default sky), up to the last bit of the
+    f64 transcendentals."""
+    from bhr_amd import HipRenderer
+    from bhr_amd.skybox import generate_skybox
+    want = generate_skybox(tex_w, tex_h, seed=42, n_stars=n_stars)
+    base = generate_skybox(tex_w, tex_h, seed=42, n_stars=n_stars, glow=False)
+    assert np.abs(want - np.clip(base, 0, 1)).max() > 0.05                    # the glow is a visible part of the sky
+    r = HipRenderer(64, 36, base, np.zeros((32, 64, 4), np.float32))
+    r.add_skybox_glow()
+    got = r.read_skybox()
+    assert got.min() >= 0.0 and got.max() <= 1.0
+    assert np.abs(got - want).max() <= 6e-8
+    assert (got != want).mean() < 1e-3                                        # and almost everywhere the same bits
+    r.close()
