@@ -13,8 +13,9 @@ def library_path() -> str:
 
 
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [
-        os.path.join(os.path.dirname(_HERE), "include", "bhr.h")]
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", "Makefile"))) + \
+        sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
 
 
 def is_stale() -> bool:

@@ -333,6 +333,48 @@ static v4 sample_disk_mip(const scene_t *s, float hit_x, float hit_y, float r_in
                    t + ((size_t)v1_h * dtex_w + u0_w) * 4, t + ((size_t)v1_h * dtex_w + u1_w) * 4, fu, fv);
 }
 
+/* ---- unit probes of the device functions (tests/test_reference_kernels.py): the shading, the LOD
+ * sampler and the tint on recorded argument lists of the reference's own @ti.func calls.  binary64
+ * across the API so that the f64 build is probed at full precision. ------------------------------- */
+ORACLE_API void oracle_probe_g_factor(const double *in16, int64_t n, double *out3)
+{   /* rows: base_color[3], hit_pos[3], hit_r, ray_dir_to_cam[3], cam_pos[3], r_inner, r_outer, tilt_rad */
+    for (int64_t k = 0; k < n; ++k) {
+        const double *a = in16 + 16 * k;
+        v3 o = apply_g_factor(v3_make((float)a[0], (float)a[1], (float)a[2]), v3_make((float)a[3], (float)a[4], (float)a[5]),
+                              (float)a[6], v3_make((float)a[7], (float)a[8], (float)a[9]),
+                              v3_make((float)a[10], (float)a[11], (float)a[12]), (float)a[13], (float)a[14], (float)a[15]);
+        out3[3 * k] = o.x; out3[3 * k + 1] = o.y; out3[3 * k + 2] = o.z;
+    }
+}
+
+ORACLE_API void oracle_probe_tint(const double *temp, int64_t n, double *out3)
+{
+    for (int64_t k = 0; k < n; ++k) {
+        v3 o = color_temp_to_tint((float)temp[k]);
+        out3[3 * k] = o.x; out3[3 * k + 1] = o.y; out3[3 * k + 2] = o.z;
+    }
+}
+
+ORACLE_API void oracle_probe_disk_mip(const f32 *disk_mips, int32_t levels, int32_t dtex_h, int32_t dtex_w,
+                                      const double *in6, int64_t n, double *out4)
+{   /* rows: hit_x, hit_y, r_inner, r_outer, t_offset, lod */
+    scene_t sc = {0, 0, 0, 0, dtex_h, dtex_w, disk_mips, levels};
+    for (int64_t k = 0; k < n; ++k) {
+        const double *a = in6 + 6 * k;
+        v4 o = sample_disk_mip(&sc, (float)a[0], (float)a[1], (float)a[2], (float)a[3], (float)a[4], (float)a[5]);
+        out4[4 * k] = o.x; out4[4 * k + 1] = o.y; out4[4 * k + 2] = o.z; out4[4 * k + 3] = o.w;
+    }
+}
+
+ORACLE_API void oracle_probe_skybox(const f32 *skybox, int32_t tex_h, int32_t tex_w, const double *dir3, int64_t n, double *out3)
+{
+    scene_t sc = {skybox, tex_h, tex_w, 0, 0, 0, 0, 0};
+    for (int64_t k = 0; k < n; ++k) {
+        v3 o = sample_skybox(&sc, v3_make((float)dir3[3 * k], (float)dir3[3 * k + 1], (float)dir3[3 * k + 2]));
+        out3[3 * k] = o.x; out3[3 * k + 1] = o.y; out3[3 * k + 2] = o.z;
+    }
+}
+
 /* ---- simplex / fbm: render.py:2269-2288 (perm), 2642-2785 --------------- */
 static const int32_t PERM256[256] = {
     151,160,137,91,90,15,131,13,201,95,96,53,194,233,7,225,

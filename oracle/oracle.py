@@ -81,6 +81,11 @@ def load(fast=False) -> C.CDLL:
     lib.oracle_set_volume.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I32]
     lib.oracle_set_escape_out.restype = None
     lib.oracle_set_escape_out.argtypes = [C.c_void_p]
+    for fn, at in (("oracle_probe_g_factor", [D, I64, D]), ("oracle_probe_tint", [D, I64, D]),
+                   ("oracle_probe_disk_mip", [F, I32, I32, I32, D, I64, D]),
+                   ("oracle_probe_skybox", [F, I32, I32, D, I64, D])):
+        getattr(lib, fn).restype = None
+        getattr(lib, fn).argtypes = at
     lib.oracle_num_threads.restype = I32
     lib.oracle_set_num_threads.argtypes = [I32]
     _libs[name] = lib
@@ -164,6 +169,45 @@ def dv2_eval(cparams, field: int, r, z=None, phi=None, norm_shear: float = 0.0, 
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
     load(fast).oracle_dv2_eval(C.byref(cparams), field, dp(rr), dp(zz), dp(pp), rr.size, norm_shear, norm_hotspot, dp(out))
     return out.reshape(shape)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def probe_g_factor(rows16, fast=False):
+    """_apply_g_factor (render.py:2439-2516) on rows of base_color[3], hit_pos[3], hit_r, ray_dir_to_cam[3],
+    cam_pos[3], r_inner, r_outer, tilt_rad -> (n, 3)."""
+    a = np.ascontiguousarray(rows16, dtype=np.float64).reshape(-1, 16)
+    out = np.empty((a.shape[0], 3), dtype=np.float64)
+    load(fast).oracle_probe_g_factor(_dp(a), a.shape[0], _dp(out))
+    return out
+
+
+def probe_tint(temps, fast=False):
+    """_color_temp_to_tint (render.py:2407-2437) -> (n, 3)."""
+    a = np.ascontiguousarray(temps, dtype=np.float64).ravel()
+    out = np.empty((a.size, 3), dtype=np.float64)
+    load(fast).oracle_probe_tint(_dp(a), a.size, _dp(out))
+    return out
+
+
+def probe_disk_mip(mips_padded, rows6, fast=False):
+    """_sample_disk_mip (render.py:2600-2637) on rows of hit_x, hit_y, r_inner, r_outer, t_offset, lod -> (n, 4)."""
+    m = np.ascontiguousarray(mips_padded, dtype=np.float32)
+    a = np.ascontiguousarray(rows6, dtype=np.float64).reshape(-1, 6)
+    out = np.empty((a.shape[0], 4), dtype=np.float64)
+    load(fast).oracle_probe_disk_mip(_fp(m), m.shape[0], m.shape[1], m.shape[2], _dp(a), a.shape[0], _dp(out))
+    return out
+
+
+def probe_skybox(skybox, dirs, fast=False):
+    """_sample_skybox (render.py:2541-2566) on unit directions -> (n, 3)."""
+    s = np.ascontiguousarray(skybox, dtype=np.float32)
+    a = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+    out = np.empty((a.shape[0], 3), dtype=np.float64)
+    load(fast).oracle_probe_skybox(_fp(s), s.shape[0], s.shape[1], _dp(a), a.shape[0], _dp(out))
+    return out
 
 
 class OracleRenderer:
