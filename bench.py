@@ -6,7 +6,9 @@ under ``python -m torch.distributed.run --nproc-per-node N`` (one rank per GPU).
 ONE JSON line.
 
 * step      one frame of the hot path: fused ray march + bloom H/V + final combine
-            (TaichiRenderer.render(), render.py:3865-3923) with the scene resident in HBM;
+            (TaichiRenderer.render(), render.py:3865-3923) with the scene resident in HBM; successive frames
+            alternate between the context's two frame slots (two HIP streams), so the tail and the bloom of
+            frame n run under the march of frame n + 1;
 * workload  BASELINE.json configs[1]: fhd 1920x1080, default scene (pov 6 0 0.5, fov 90,
             step_size 0.1, disk 2-15, tilt 0, AA off), procedural disk texture + skybox;
 * N > 1     the path shards by independent frames (configs[4], frames f % N == rank): every
@@ -51,7 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--persistent", action="store_true", help="A/B: persistent waves + queue refill instead of the tile schedule")
     ap.add_argument("--no-other-math", action="store_true", help="skip the informational A/B leg (profiling)")
-    ap.add_argument("--no-two-streams", action="store_true", help="skip the informational two-stream leg")
+    ap.add_argument("--frame-slots", type=int, default=None, choices=[1, 2],
+                    help="frames in flight per context (default 2: successive frames overlap on two streams)")
     ap.add_argument("--math", default=None, choices=["fast", "strict"], help="march arithmetic (default: the renderer's)")
     return ap.parse_args()
 
@@ -122,7 +125,8 @@ def main():
 
     from bhr_amd import workloads
     wl = WORKLOADS[args.workload]
-    renderer, sky, tex, scene_note = workloads.make_scene(wl, device_index=local_rank, math=args.math)
+    renderer, sky, tex, scene_note = workloads.make_scene(wl, device_index=local_rank, math=args.math,
+                                                          frame_slots=args.frame_slots)
 
     def barrier():
         if dist is not None:
@@ -159,45 +163,54 @@ def main():
     renderer.sync()
     el_other = time.perf_counter() - t1
     co = renderer.counters() if n_other else None
-    # informational: the same frames alternating between two contexts = two HIP streams on this GPU.  Kernels of
-    # the two streams overlap (the tail of one march under the head of the next, the bloom under a march), so
-    # per-launch durations no longer describe one kernel: the headline line and its roofline stay on one stream.
-    two = None
-    if world == 1 and not args.no_two_streams and not args.no_other_math:
-        second, _, _, _ = workloads.make_scene(wl, device_index=local_rank, math=args.math)
-        n2 = max(args.steps // 2, 10)
-        for _ in range(5):
-            renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
-            second.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
-        renderer.sync(); second.sync()
+    # Per-kernel durations of ISOLATED launches (one frame slot, one stream): in the timed region above two frames
+    # are in flight, their kernels overlap and a launch's own event bracket also covers time it shares with the
+    # other frame's kernels.  The roofline below describes the kernel, so it is taken from launches that have the
+    # chip to themselves: the same scene and view on a second context created with one frame slot, outside the
+    # timed region.  (`rocprofv3 --kernel-trace` of `bench.py --frame-slots 1` is the matching profile.)
+    iso = None
+    if renderer.frame_slots != 1 and rank == 0:
+        solo, _, _, _ = workloads.make_scene(wl, device_index=local_rank, math=args.math, frame_slots=1)
+        n_iso = max(min(args.steps, 100), 10)
+        for _ in range(10):
+            solo.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
+        solo.timing_reset()
+        solo.sync()
         t2 = time.perf_counter()
-        for _ in range(n2):
-            renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
-            second.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
-        renderer.sync(); second.sync()
-        el2 = time.perf_counter() - t2
-        two = {"streams": 2, "fps": 2 * n2 / el2, "value": 2 * n2 * float(steps_per_frame) / el2 / 1e6, "unit": "Mray-steps/s",
-               "note": "informational: two contexts alternate frames on this GPU, their kernels overlap; `value` above is one stream"}
-        second.close()
+        for _ in range(n_iso):
+            solo.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
+        solo.sync()
+        el_iso = time.perf_counter() - t2
+        ci = solo.counters()
+        iso = {"march_ms": ci["march_ms_sum"] / max(ci["frames_timed"], 1), "post_ms": ci["bloom_ms_sum"] / max(ci["frames_timed"], 1),
+               "frames": ci["frames_timed"], "fps": n_iso / el_iso, "ray_steps": ci["ray_steps_sum"] / max(ci["frames_timed"], 1)}
+        solo.close()
     # MAX over ranks of the time, SUM over ranks of the ray-steps each rank marched in the timed region
     elapsed, total_steps = D.aggregate_throughput(elapsed, float(c["ray_steps_sum"]) if c["frames_timed"] == args.steps
                                                   else float(steps_per_frame) * args.steps, dist, device=red_dev)
 
     if rank == 0:
         n_frames = c["frames_timed"]
-        march_ms = c["march_ms_sum"] / max(n_frames, 1)
-        bloom_ms = c["bloom_ms_sum"] / max(n_frames, 1)
+        overlapped = {"march": c["march_ms_sum"] / max(n_frames, 1), "post": c["bloom_ms_sum"] / max(n_frames, 1),
+                      "frames_timed": n_frames}
+        if iso is not None:
+            march_ms, bloom_ms, k_frames, k_steps = iso["march_ms"], iso["post_ms"], iso["frames"], iso["ray_steps"]
+        else:   # one frame slot: the timed region's own launches are isolated
+            march_ms, bloom_ms, k_frames = overlapped["march"], overlapped["post"], n_frames
+            k_steps = c["ray_steps_sum"] / max(n_frames, 1)
         pixels = wl["width"] * wl["height"]
         alg_bytes = MARCH_BYTES_PER_PIXEL * pixels
         achieved_gbs = alg_bytes / (march_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "march_traffic.json")
         if os.path.isfile(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.workload)
+                traffic_source = tj.get("source")
             except Exception:
                 traffic = None
-        valu_tflops = MARCH_FLOP_PER_RAY_STEP * (c["ray_steps_sum"] / max(n_frames, 1)) / (march_ms * 1e-3) / 1e12
+        valu_tflops = MARCH_FLOP_PER_RAY_STEP * k_steps / (march_ms * 1e-3) / 1e12
         out = {
             "metric": "Mray-steps/s", "value": total_steps / elapsed / 1e6, "unit": "Mray-steps/s",
             "fps": world * args.steps / elapsed,
@@ -210,12 +223,16 @@ def main():
                        "scene": scene_note, "frames_per_rank": args.steps,
                        "sharding": "independent frames per rank, no collective",
                        "march_schedule": "persistent+refill" if args.persistent else "tile",
-                       "march_math": renderer.math,
+                       "march_math": renderer.math, "frame_slots": renderer.frame_slots,
                        "ray_steps_per_frame": int(steps_per_frame), "steps_per_ray": steps_per_frame / pixels},
-            "kernel_ms": {"march": march_ms, "bloom_combine_flare" if flare else "bloom_and_combine": bloom_ms, "frames_timed": n_frames,
-                          "march_vgprs": c["march_vgprs"]},
+            "kernel_ms": {"march": march_ms, "bloom_combine_flare" if flare else "bloom_and_combine": bloom_ms, "frames_timed": k_frames,
+                          "march_vgprs": c["march_vgprs"],
+                          "how": "HIP events on the launching stream, isolated launches (one frame slot)"
+                                 + ("" if iso is None else f", {iso['fps']:.0f} fps one frame at a time")},
+            "kernel_ms_in_timed_region": dict(overlapped, note="event brackets of overlapping launches (two frame slots): "
+                                              "each covers time shared with the other frame's kernels"),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "march", "algorithmic_bytes_per_launch": alg_bytes},
             # the march is not HBM bound: the governing ceiling is non-matrix FP32
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_FP32_PEAK_TFLOPS,
@@ -226,8 +243,6 @@ def main():
           out["other_math"] = {"math": other, "value": co["ray_steps"] * n_other / el_other / 1e6, "unit": "Mray-steps/s",
                              "fps": n_other / el_other, "march_ms": co["march_ms_sum"] / max(co["frames_timed"], 1),
                              "note": "informational A/B in the same process; `value` above is the default (parity-certified) arithmetic"}
-        if two:
-            out["two_streams"] = two
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, sky, tex)
         sys.stdout.flush()

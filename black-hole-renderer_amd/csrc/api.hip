@@ -23,9 +23,52 @@ int32_t dev_alloc(T **p, size_t count) {
     return BHR_OK;
 }
 
-int32_t use_device(bhr_ctx *ctx) {
-    BHR_HIP(hipSetDevice(ctx->cfg.device));
+int32_t use_device(bhr_ctx *ctx) { return bhr_enter(ctx); }
+
+// points the launchers' view of the frame buffers (ctx->d_bg ...) at slot k
+void activate_slot(bhr_ctx *ctx, int k) {
+    const bhr_frame_slot &f = ctx->slots[k];
+    ctx->d_bg = f.d_bg;
+    ctx->d_disk = f.d_disk;
+    ctx->d_hblur = f.d_hblur;
+    ctx->d_blur = f.d_blur;
+    ctx->d_final = f.d_final;
+    ctx->d_final_u8 = f.d_final_u8;
+    ctx->d_queue = f.d_queue;
+    ctx->active_slot = k;
+}
+
+int32_t alloc_slot(bhr_ctx *ctx, int k) {
+    bhr_frame_slot &f = ctx->slots[k];
+    if (f.allocated) return BHR_OK;
+    const size_t W = ctx->cfg.width, rows = ctx->rows, R = ctx->bloom_R, px3 = rows * W * 3;
+    if (!f.stream) {
+        if (k == 0 && ctx->n_slots == 1) f.stream = ctx->scene_stream;
+        else BHR_HIP(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+    }
+    if (!f.done) BHR_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+    BHR_TRY(dev_alloc(&f.d_bg, px3));
+    BHR_TRY(dev_alloc(&f.d_disk, px3));
+    BHR_TRY(dev_alloc(&f.d_blur, px3));
+    BHR_TRY(dev_alloc(&f.d_final, px3));
+    BHR_TRY(dev_alloc(&f.d_final_u8, px3));
+    BHR_TRY(dev_alloc(&f.d_hblur, 3 * (rows + 2 * R) * W));
+    BHR_TRY(dev_alloc(&f.d_queue, 1));
+    // the halo rows of the H-blur buffer outside the image stay zero for the life of the context
+    BHR_HIP(hipMemsetAsync(f.d_hblur, 0, 3 * (rows + 2 * R) * W * sizeof(float), ctx->scene_stream));
+    BHR_HIP(hipStreamSynchronize(ctx->scene_stream));
+    f.allocated = 1;
     return BHR_OK;
+}
+
+void free_slot(bhr_ctx *ctx, int k) {
+    bhr_frame_slot &f = ctx->slots[k];
+    void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur, f.d_queue};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (f.done) (void)hipEventDestroy(f.done);
+    if (f.stream && f.stream != ctx->scene_stream) (void)hipStreamDestroy(f.stream);
+    memset(&f, 0, sizeof(f));
 }
 
 int32_t ensure_pinned(bhr_ctx *ctx, size_t bytes) {
@@ -143,6 +186,17 @@ int32_t bhr_fail(int32_t code, const char *fmt, ...) {
     return code;
 }
 
+int32_t bhr_enter(bhr_ctx *ctx) {
+    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    for (int k = 0; k < 2; ++k) {
+        bhr_frame_slot &f = ctx->slots[k];
+        if (f.in_flight && f.stream != ctx->scene_stream) BHR_HIP(hipStreamWaitEvent(ctx->scene_stream, f.done, 0));
+        f.in_flight = 0;
+    }
+    ctx->stream = ctx->scene_stream;
+    return BHR_OK;
+}
+
 extern "C" {
 
 const char *bhr_last_error(void) { return g_err; }
@@ -175,6 +229,12 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     auto bail = [&](int32_t rc) { bhr_destroy(ctx); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipSetDevice(%d) failed", cfg->device));
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipStreamCreate failed"));
+    ctx->scene_stream = ctx->stream;
+    {
+        const char *e = getenv("BHR_FRAME_SLOTS");       // 2 (default): frames alternate between two slots / streams
+        ctx->n_slots = (e && atoi(e) == 1) ? 1 : 2;
+    }
+    if (hipEventCreateWithFlags(&ctx->scene_ev, hipEventDisableTiming) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipEventCreate failed"));
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipEventCreate failed"));
     for (auto &e : ctx->ring_ev)
@@ -183,22 +243,17 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     const size_t W = cfg->width, H = cfg->height, rows = ctx->rows, R = ctx->bloom_R;
     const size_t px3 = rows * W * 3;
     int32_t rc;
-    if ((rc = dev_alloc(&ctx->d_bg, px3))) return bail(rc);
-    if ((rc = dev_alloc(&ctx->d_disk, px3))) return bail(rc);
-    if ((rc = dev_alloc(&ctx->d_blur, px3))) return bail(rc);
-    if ((rc = dev_alloc(&ctx->d_final, px3))) return bail(rc);
-    if ((rc = dev_alloc(&ctx->d_final_u8, px3))) return bail(rc);
-    if ((rc = dev_alloc(&ctx->d_hblur, 3 * (rows + 2 * R) * W))) return bail(rc);
+    (void)px3;
+    if ((rc = alloc_slot(ctx, 0))) return bail(rc);
+    activate_slot(ctx, 0);
     if ((rc = dev_alloc(&ctx->d_wtab, 3 * (R + 1 + 64)))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_wext, 3 * (2 * (R + 4) + 8)))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_wsum_h, 3 * W))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_wsum_v, 3 * H))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_ray_steps, BHR_STEP_CELL))) return bail(rc);
-    if ((rc = dev_alloc(&ctx->d_queue, 1))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_steps_ring, (size_t)BHR_TIMING_RING * BHR_STEP_CELL))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_steps_fold, BHR_TIMING_RING))) return bail(rc);
-    if (hipMemsetAsync(ctx->d_hblur, 0, 3 * (rows + 2 * R) * W * sizeof(float), ctx->stream) != hipSuccess ||
-        hipMemsetAsync(ctx->d_ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream) != hipSuccess ||
+    if (hipMemsetAsync(ctx->d_ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream) != hipSuccess ||
         hipMemsetAsync(ctx->d_steps_ring, 0, sizeof(unsigned long long) * BHR_TIMING_RING * BHR_STEP_CELL, ctx->stream) != hipSuccess)
         return bail(bhr_fail(BHR_ERR_HIP, "hipMemsetAsync failed"));
     int32_t v = 0, l = 0;
@@ -218,11 +273,17 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
 void bhr_destroy(bhr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &f : ctx->slots)
+        if (f.stream) (void)hipStreamSynchronize(f.stream);
+    if (ctx->scene_stream) (void)hipStreamSynchronize(ctx->scene_stream);
+    ctx->stream = ctx->scene_stream;
     free_scene(ctx);
     free_bg(ctx);
-    void *bufs[] = {ctx->d_skybox, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_final_u8, ctx->d_hblur,
-                    ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_queue, ctx->d_noise_in,
+    free_slot(ctx, 0);
+    free_slot(ctx, 1);
+    if (ctx->scene_ev) (void)hipEventDestroy(ctx->scene_ev);
+    void *bufs[] = {ctx->d_skybox,
+                    ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_noise_in,
                     ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params, ctx->d_glow_hw, ctx->d_glow_wh,
                     ctx->d_flare_c0, ctx->d_flare_c12, ctx->d_flare_prog, ctx->d_flare_sums, ctx->d_tile_order, ctx->d_row_steps};
     for (void *b : bufs)
@@ -412,27 +473,63 @@ int32_t bhr_eval_noise(bhr_ctx *ctx, const float *coords, int64_t n, int32_t mod
     return download(ctx, out, ctx->d_noise_out, (size_t)n * sizeof(float));
 }
 
-int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
-    if (!ctx || !cam) return bhr_fail(BHR_ERR_INVALID, "bhr_render: null argument");
-    BHR_TRY(use_device(ctx));
-    const int slot = (int)(ctx->ring_head % BHR_TIMING_RING);
-    ctx->cur_slot = slot;
-    BHR_TRY(bhr_launch_march(ctx, cam, flags));  // records ev[0]/ev[1] and the ring's march events
+// One frame: march -> bloom H -> bloom V + combine (-> lens flare).  Frames alternate between the context's two
+// frame slots (bhr_frame_slot): frame n + 1 is launched on the other slot's stream into its own buffers and overlaps
+// the tail and the post-passes of frame n.  The scene is only read; everything that writes it or reads a frame goes
+// through bhr_enter, which orders the scene stream behind both slots.
+namespace {
+int32_t render_on_slot(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags, int k, int ring) {
+    bhr_frame_slot &f = ctx->slots[k];
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
+    BHR_TRY(bhr_launch_march(ctx, cam, flags));  // records the ring slot's march events
     if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctx));
-    ctx->v_zero_cell = ctx->d_steps_ring + (size_t)((slot + 1) % BHR_TIMING_RING) * BHR_STEP_CELL;
+    // the V kernel clears the counter cell of the frame after next: that frame runs on THIS stream again, whereas
+    // the next frame's march may already be counting on the other stream
+    ctx->v_zero_cell = ctx->d_steps_ring + (size_t)((ring + 2) % BHR_TIMING_RING) * BHR_STEP_CELL;
     const int32_t rc_v = bhr_launch_bloom_v(ctx, with_bloom);
     ctx->v_zero_cell = nullptr;
     BHR_TRY(rc_v);
     if (flags & BHR_LENS_FLARE) {
         if (ctx->rows != ctx->cfg.height)
             return bhr_fail(BHR_ERR_INVALID, "bhr_render: the lens flare needs whole-frame sums; use bhr_group_render for row blocks");
+        // the flare's scratch buffers are shared by the slots: wait for the other frame's passes
+        bhr_frame_slot &o = ctx->slots[k ^ 1];
+        if (o.in_flight && o.stream != f.stream) BHR_HIP(hipStreamWaitEvent(f.stream, o.done, 0));
         BHR_TRY(bhr_launch_flare_glow(ctx, true));
         BHR_TRY(bhr_launch_flare_sums(ctx));
         BHR_TRY(bhr_launch_flare_apply(ctx, nullptr));
     }
-    BHR_HIP(hipEventRecord(ctx->ring_ev[slot * 3 + 2], ctx->stream));
-    ctx->last_slot = slot;
+    BHR_HIP(hipEventRecord(ctx->ring_ev[ring * 3 + 2], f.stream));
+    BHR_HIP(hipEventRecord(f.done, f.stream));
+    return BHR_OK;
+}
+}  // namespace
+
+int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
+    if (!ctx || !cam) return bhr_fail(BHR_ERR_INVALID, "bhr_render: null argument");
+    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    ctx->stream = ctx->scene_stream;
+    // launches that use per-context scratch (work queue of the persistent schedule, row-cost profile) stay on one slot
+    const bool exclusive = (flags & (BHR_PERSISTENT | BHR_ROW_COSTS)) != 0;
+    if (exclusive) BHR_TRY(bhr_enter(ctx));
+    const int k = (ctx->n_slots == 2 && !exclusive) ? ctx->next_slot : 0;
+    BHR_TRY(alloc_slot(ctx, k));
+    bhr_frame_slot &f = ctx->slots[k];
+    if (!(flags & BHR_SKIP_BLOOM)) BHR_TRY(bhr_bloom_prepare(ctx));   // one-off tables, on the scene stream
+    if (f.stream != ctx->scene_stream) {
+        BHR_HIP(hipEventRecord(ctx->scene_ev, ctx->scene_stream));    // everything the scene stream has been given so far
+        BHR_HIP(hipStreamWaitEvent(f.stream, ctx->scene_ev, 0));
+    }
+    const int ring = (int)(ctx->ring_head % BHR_TIMING_RING);
+    ctx->cur_slot = ring;
+    activate_slot(ctx, k);
+    ctx->stream = f.stream;
+    const int32_t rc = render_on_slot(ctx, cam, flags, k, ring);
+    ctx->stream = ctx->scene_stream;
+    f.in_flight = 1;
+    BHR_TRY(rc);
+    if (ctx->n_slots == 2 && !exclusive) ctx->next_slot = k ^ 1;
+    ctx->last_slot = ring;
     ctx->ring_head += 1;
     ctx->last_flags = (int32_t)flags;
     ctx->timing_valid = 1;
@@ -518,7 +615,8 @@ int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {
         ctx->counters.frame_ms = ev_ms(e[0], e[2]);
     }
     {
-        const int64_t n = ctx->ring_head < BHR_TIMING_RING ? ctx->ring_head : BHR_TIMING_RING;
+        // the two cells after the head have been cleared for the frames to come: at most RING - 2 frames are on record
+        const int64_t n = ctx->ring_head < BHR_TIMING_RING - 2 ? ctx->ring_head : BHR_TIMING_RING - 2;
         float ms_m = 0.0f, ms_b = 0.0f;
         unsigned long long steps_sum = 0;
         if (n > 0) {

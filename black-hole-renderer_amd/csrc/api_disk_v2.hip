@@ -25,7 +25,7 @@ extern "C" int32_t bhr_disk_v2_eval(bhr_ctx *ctx, const bhr_disk_v2_params *p, i
     const bool needs_phi = field >= BHR_DV2_F_MODE;
     if ((needs_z && !z) || (needs_phi && !phi)) return bhr_fail(BHR_ERR_INVALID, "bhr_disk_v2_eval: field %d needs %s", field, needs_z ? "z" : "phi");
     if (n == 0) return BHR_OK;
-    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    BHR_TRY(bhr_enter(ctx));
     DevBuf dr, dz, dphi, dout, daux, dmax;
     const size_t bytes = (size_t)n * sizeof(double);
     int32_t rc;
@@ -53,7 +53,7 @@ extern "C" int32_t bhr_set_disk_source(bhr_ctx *ctx, int32_t source, const bhr_d
                                        double norm_hotspot, double t_peak) {
     if (!ctx || (source != BHR_DISK_TEXTURE && source != BHR_DISK_V2 && source != BHR_DISK_V2_VOLUME))
         return bhr_fail(BHR_ERR_INVALID, "bhr_set_disk_source: bad argument");
-    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    BHR_TRY(bhr_enter(ctx));
     if (source != BHR_DISK_TEXTURE) {
         if (!p || !(norm_shear > 0.0) || !(norm_hotspot > 0.0) || !(t_peak > 0.0))
             return bhr_fail(BHR_ERR_INVALID, "bhr_set_disk_source: Disk V2 needs parameters and positive normalisation constants");

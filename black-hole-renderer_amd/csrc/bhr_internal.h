@@ -73,10 +73,29 @@ struct BhrMarchArgs {
     int32_t tiles_x;
 };
 
+// Frame slot: the buffers one frame in flight owns.  bhr_render alternates between two slots, each with its own
+// stream, so that the tail and the bloom of frame n run under the march of frame n + 1; the scene (skybox, mip
+// stack, comp planes ...) is shared and read-only while frames are in flight (bhr_enter orders every other entry
+// point behind them).  Slot 1 is allocated at the second bhr_render; BHR_FRAME_SLOTS=1 keeps one slot on the
+// context's own stream (round 1 behaviour, isolated per-kernel timing).
+struct bhr_frame_slot {
+    hipStream_t stream;
+    float *d_bg, *d_disk, *d_hblur, *d_blur, *d_final;
+    uint8_t *d_final_u8;
+    unsigned int *d_queue;
+    hipEvent_t done;        // end of the slot's last bhr_render
+    int32_t allocated;
+    int32_t in_flight;      // rendered since the last join
+};
+
 struct bhr_ctx {
     bhr_config cfg;
     int32_t rows;
-    hipStream_t stream;
+    hipStream_t stream;                 // the stream launchers use: the scene stream, or a slot's during bhr_render
+    hipStream_t scene_stream;           // scene updates, read-backs, group renders
+    bhr_frame_slot slots[2];
+    int32_t n_slots, next_slot, active_slot;
+    hipEvent_t scene_ev;                // scene stream -> slot stream ordering, recorded at every bhr_render
     hipEvent_t ev[8];
     // per-frame timing ring: 3 events per bhr_render (march start, march end, frame end)
     hipEvent_t ring_ev[BHR_TIMING_RING * 3];
@@ -166,6 +185,10 @@ int32_t bhr_fail(int32_t code, const char *fmt, ...);
         int32_t rc__ = (expr);           \
         if (rc__ != BHR_OK) return rc__; \
     } while (0)
+
+// Every API entry point except bhr_render: selects the device and orders the scene stream behind the frames in
+// flight, so that scene writes, read-backs and stand-alone passes see (and never race with) a finished frame.
+int32_t bhr_enter(bhr_ctx *ctx);
 
 // launchers (each lives next to its kernels)
 int32_t bhr_launch_march(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);         // dispatches on math_mode

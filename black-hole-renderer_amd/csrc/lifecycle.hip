@@ -205,7 +205,7 @@ int32_t bhr_entity_profile_upload(bhr_ctx *ctx, const float *density, const floa
                                   int64_t *offset_out) {
     if (!ctx || !density || !temp || n_rows <= 0 || !offset_out) return bhr_fail(BHR_ERR_INVALID, "bhr_entity_profile_upload: bad argument");
     if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call init_background_layer() first");
-    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    BHR_TRY(bhr_enter(ctx));
     const int64_t need = 2ll * n_rows * ctx->bg_n_phi;
     if (ctx->pool_used + need > ctx->pool_cap) {   // grow geometrically, keep the contents
         int64_t cap = ctx->pool_cap ? ctx->pool_cap : (int64_t)64 * ctx->bg_n_phi * 64;
@@ -233,7 +233,7 @@ int32_t bhr_accumulate_entities(bhr_ctx *ctx, const bhr_filament_row *fil, const
                                 const bhr_rolled_row *rolled, const int32_t *rol_ptr, const double *phi) {
     if (!ctx || !fil_ptr || !rol_ptr || !phi) return bhr_fail(BHR_ERR_INVALID, "bhr_accumulate_entities: bad argument");
     if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call init_background_layer() first");
-    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    BHR_TRY(bhr_enter(ctx));
     const int n_r = ctx->bg_n_r, n_phi = ctx->bg_n_phi;
     const int n_fil = fil_ptr[n_r], n_rol = rol_ptr[n_r];
     if ((n_fil > 0 && !fil) || (n_rol > 0 && !rolled)) return bhr_fail(BHR_ERR_INVALID, "bhr_accumulate_entities: missing pair table");
@@ -267,7 +267,7 @@ int32_t bhr_accumulate_entities(bhr_ctx *ctx, const bhr_filament_row *fil, const
 int32_t bhr_stats_prepare(bhr_ctx *ctx, int32_t enable_rt, uint64_t *n_positive_out) {
     if (!ctx || !n_positive_out) return bhr_fail(BHR_ERR_INVALID, "bhr_stats_prepare: bad argument");
     if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call init_background_layer() first");
-    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    BHR_TRY(bhr_enter(ctx));
     int32_t rc = ensure_scratch(ctx);
     if (rc) return rc;
     const int n_r = ctx->bg_n_r, n_phi = ctx->bg_n_phi;
@@ -294,7 +294,7 @@ int32_t bhr_stats_prepare(bhr_ctx *ctx, int32_t enable_rt, uint64_t *n_positive_
 int32_t bhr_stats_select(bhr_ctx *ctx, int32_t which, uint64_t rank, float *value_out) {
     if (!ctx || !value_out || (which != 0 && which != 1)) return bhr_fail(BHR_ERR_INVALID, "bhr_stats_select: bad argument");
     if (!ctx->bg_ready || !ctx->stats_prepared) return bhr_fail(BHR_ERR_STATE, "bhr_stats_select: call bhr_stats_prepare first");
-    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    BHR_TRY(bhr_enter(ctx));
     const long long n = (long long)ctx->bg_n_r * ctx->bg_n_phi;
     float *d_density = ctx->d_stats_scratch, *d_ts = d_density + n;
     unsigned int *d_hist = (unsigned int *)(d_ts + n);
@@ -304,7 +304,7 @@ int32_t bhr_stats_select(bhr_ctx *ctx, int32_t which, uint64_t rank, float *valu
 int32_t bhr_stats_row_statistics(bhr_ctx *ctx, float div, int32_t lo, int32_t hi, float *rows_out) {
     if (!ctx || !rows_out) return bhr_fail(BHR_ERR_INVALID, "bhr_stats_row_statistics: bad argument");
     if (!ctx->bg_ready || !ctx->stats_prepared) return bhr_fail(BHR_ERR_STATE, "bhr_stats_row_statistics: call bhr_stats_prepare first");
-    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    BHR_TRY(bhr_enter(ctx));
     const int n_r = ctx->bg_n_r, n_phi = ctx->bg_n_phi;
     if (lo < 0 || hi < lo || hi >= n_phi) return bhr_fail(BHR_ERR_INVALID, "bhr_stats_row_statistics: bad indices %d %d", lo, hi);
     int n_pad = 1;

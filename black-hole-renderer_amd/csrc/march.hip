@@ -84,14 +84,15 @@ __device__ __forceinline__ float q_rsq(float x) { return __builtin_amdgcn_rsqf(x
 __device__ __forceinline__ float q_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float q_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-// Correctly rounded x / 6 in three operations (Markstein: q = RN(x c), r = x - 6 q exactly by FMA,
-// q' = RN(q + r c) with c = RN(1/6)); tests/test_div6.py checks it against IEEE division on every
-// f32 significand.  Replaces six ~10-instruction IEEE divisions per RK4 step in the strict build.
+// Correctly rounded x / 6 in TWO operations: 1/6 = c_hi + c_lo up to 2^-50 (c_hi = RN(1/6), c_lo = RN(1/6 - c_hi)),
+//   q = RN(x c_hi + RN(x c_lo)).
+// The argument of the final rounding is within 2^-48 (relative) of x / 6, and x / 6 is never closer than 1/6 ulp to
+// a rounding boundary (6 q = integer significand => the fractional position is a multiple of 1/3 of half an ulp),
+// so the rounding is the correct one for every normal x.  tests/test_div6.py checks it against IEEE division on
+// every f32 significand, bhr_selftest() on the device.  (Round 1 used the generic 3-operation Markstein sequence.)
 __device__ __forceinline__ float div6(float x) {
-    const float c = 0x1.555556p-3f;
-    float q = x * c;
-    float r = fmaf(-6.0f, q, x);
-    return fmaf(r, c, q);
+    const float c_hi = 0x1.555556p-3f, c_lo = -0x1.555556p-28f;
+    return fmaf(x, c_hi, x * c_lo);
 }
 
 // IEEE-754 correctly rounded sqrt, reciprocal and divide for NORMAL-range operands (no overflow or
@@ -555,14 +556,14 @@ struct Ray {
     // from stretching live ranges across the whole step (4k AA: 6.7 ms against 7.6 ms unconditional).
     static constexpr bool kRedo = DIFF;
     __device__ __forceinline__ bool step(const BhrMarchArgs &a) {
-        float r_safe = fmaxf(r, BHR_RS + 1e-3f);
-        float far_scale = sqrt_rn(r_safe);               // sqrt(r_safe / r_cap), r_cap = 1
-        if (far_scale > 10.0f) far_scale = 10.0f;
+        // clamps as single v_med3 / v_min instructions (no NaN can reach them: r is a finite norm); the C forms cost a
+        // canonicalising v_max, and compare + select pairs
+        float r_safe;                                    // max(r, r_cap + 1e-3) without the canonicalising second v_max
+        asm("v_max_f32 %0, %1, %2" : "=v"(r_safe) : "v"(r), "v"(BHR_RS + 1e-3f));
+        float far_scale = __builtin_fminf(sqrt_rn(r_safe), 10.0f);   // sqrt(r_safe / r_cap), r_cap = 1; capped at max_fac
         float q = rcp_rn(r_safe);                        // r_cap / r_safe, r_cap = 1
-        float near_damp = rcp_rn(1.0f + 2.0f * (q * q * q));
-        float dt_fac = far_scale * near_damp;
-        if (dt_fac < 0.2f) dt_fac = 0.2f;
-        if (dt_fac > 10.0f) dt_fac = 10.0f;
+        float near_damp = rcp_rn(fmaf(2.0f, q * q * q, 1.0f));   // 2 x is exact: one rounding, as 1 + 2 x has
+        float dt_fac = __builtin_amdgcn_fmed3f(far_scale * near_damp, 0.2f, 10.0f);   // render.py:2865-2868
         float h = a.h_base * dt_fac;
 
         float f1 = coef(r2p, r);

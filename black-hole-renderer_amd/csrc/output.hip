@@ -313,8 +313,9 @@ int32_t bhr_sink_submit(bhr_sink *s, const char *path) {
         s->in_flight += 1;
     }
     bhr_ctx *ctx = s->ctx;
-    hipError_t e = hipSetDevice(ctx->cfg.device);
-    int32_t rc = e == hipSuccess ? bhr_launch_quantize(ctx) : BHR_ERR_HIP;
+    hipError_t e = hipSuccess;
+    int32_t rc = bhr_enter(ctx);            // the scene stream follows the frame in flight; quantise + copy queue behind it
+    if (rc == BHR_OK) rc = bhr_launch_quantize(ctx);
     if (rc == BHR_OK) {
         e = hipMemcpyAsync(s->slots[slot].host, ctx->d_final_u8, s->frame_bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(s->slots[slot].ev, ctx->stream);

@@ -51,7 +51,7 @@ extern "C" int32_t bhr_skybox_add_glow(bhr_ctx *ctx) {
     if (!ctx) return bhr_fail(BHR_ERR_INVALID, "bhr_skybox_add_glow: null ctx");
     if (!ctx->d_skybox) return bhr_fail(BHR_ERR_STATE, "bhr_skybox_add_glow: no skybox set (bhr_set_skybox)");
     if (ctx->sky_h < 2 || ctx->sky_w < 2) return bhr_fail(BHR_ERR_INVALID, "bhr_skybox_add_glow: skybox %dx%d too small", ctx->sky_h, ctx->sky_w);
-    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    BHR_TRY(bhr_enter(ctx));
     const double PI = 3.141592653589793;
     const long long n = (long long)ctx->sky_h * ctx->sky_w;
     hipLaunchKernelGGL(sky_glow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_skybox, ctx->sky_h,
@@ -63,7 +63,7 @@ extern "C" int32_t bhr_skybox_add_glow(bhr_ctx *ctx) {
 extern "C" int32_t bhr_get_skybox(bhr_ctx *ctx, float *out) {
     if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_get_skybox: bad argument");
     if (!ctx->d_skybox) return bhr_fail(BHR_ERR_STATE, "bhr_get_skybox: no skybox set");
-    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    BHR_TRY(bhr_enter(ctx));
     BHR_HIP(hipMemcpyAsync(out, ctx->d_skybox, (size_t)ctx->sky_h * ctx->sky_w * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     BHR_HIP(hipStreamSynchronize(ctx->stream));
     return BHR_OK;

@@ -8,6 +8,7 @@ lens flare, which the reference also does in NumPy (render.py:3925-4028).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -46,7 +47,8 @@ class HipRenderer:
                  r_disk_inner=R_DISK_INNER_DEFAULT, r_disk_outer=R_DISK_OUTER_DEFAULT,
                  disk_tilt=0.0, lens_flare=False, anti_alias="disabled", aa_strength=1.0,
                  disk_rotation_speed=0.1, ignore_taichi_cache=False,
-                 device_index: int = 0, rows: Optional[Sequence[int]] = None, math: str = "strict"):
+                 device_index: int = 0, rows: Optional[Sequence[int]] = None, math: str = "strict",
+                 frame_slots: Optional[int] = None):
         if device not in ("hip", "gpu"):
             raise ValueError(f"HipRenderer runs on the GPU only (device={device!r}); there is no CPU path")
         # math="strict" (default): the RK4 loop in the reference's operation order with IEEE sqrt and
@@ -74,8 +76,24 @@ class HipRenderer:
                           0 if anti_alias == "disabled" else 1, float(aa_strength), float(disk_rotation_speed),
                           self.device_index, _lib.MATH_STRICT if math == "strict" else _lib.MATH_FAST)
         handle = C.c_void_p()
-        _lib.check(self._lib.bhr_create(C.byref(cfg), C.byref(handle)))
+        # frame_slots: 2 (library default) = successive render_async calls alternate between two frame slots /
+        # streams and overlap; 1 = one frame at a time on the context's stream (isolated kernel timing).  The
+        # library reads BHR_FRAME_SLOTS when the context is created.
+        if frame_slots not in (None, 1, 2):
+            raise ValueError(f"frame_slots must be 1 or 2, got {frame_slots!r}")
+        saved = os.environ.get("BHR_FRAME_SLOTS")
+        if frame_slots is not None:
+            os.environ["BHR_FRAME_SLOTS"] = str(frame_slots)
+        try:
+            _lib.check(self._lib.bhr_create(C.byref(cfg), C.byref(handle)))
+        finally:
+            if frame_slots is not None:
+                if saved is None:
+                    os.environ.pop("BHR_FRAME_SLOTS", None)
+                else:
+                    os.environ["BHR_FRAME_SLOTS"] = saved
         self._ctx = handle
+        self.frame_slots = frame_slots if frame_slots is not None else (1 if saved == "1" else 2)
 
         skybox = np.ascontiguousarray(skybox, dtype=np.float32)
         disk_tex = np.ascontiguousarray(disk_tex, dtype=np.float32)

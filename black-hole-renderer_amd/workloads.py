@@ -7,7 +7,7 @@ from .renderer import HipRenderer
 from .textures import compute_disk_texture_resolution
 
 
-def make_scene(wl: dict, device_index: int = 0, n_stars: int = 6000, math=None):
+def make_scene(wl: dict, device_index: int = 0, n_stars: int = 6000, math=None, frame_slots=None):
     """Renderer for workload ``wl`` (see bench.WORKLOADS) with the reference's default scene:
     procedural skybox (generate_skybox(2048, 1024, seed 42)) and the lifecycle disk texture at
     t = 0 (render_image, render.py:4044-4069).  Returns (renderer, skybox, disk_tex, note)."""
@@ -21,7 +21,7 @@ def make_scene(wl: dict, device_index: int = 0, n_stars: int = 6000, math=None):
     placeholder = np.zeros((n_r, n_phi, 4), dtype=np.float32)
     r = HipRenderer(W, H, sky, placeholder, step_size=wl["step_size"], r_max=10.0, r_disk_inner=r_in,
                     r_disk_outer=r_out, disk_tilt=wl["disk_tilt"], anti_alias=wl["anti_alias"],
-                    device_index=device_index, **({} if math is None else {"math": math}))
+                    device_index=device_index, frame_slots=frame_slots, **({} if math is None else {"math": math}))
     r.add_skybox_glow()
     sky = r.read_skybox()
     factories = init_lifecycle_system(r, n_r, n_phi, seed=42)

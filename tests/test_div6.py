@@ -1,4 +1,4 @@
-"""The strict march divides by 6 with a 3-operation Markstein sequence (csrc/march.hip: div6).
+"""The strict march divides by 6 with a 2-operation sequence, q = RN(x c_hi + RN(x c_lo)) (csrc/march.hip: div6).
 It must equal IEEE x / 6.0f for every f32 significand; checked exhaustively on the CPU with the
 same fmaf sequence (one binade covers all significands, a few exponents cover the rest of the
 range incl. negatives)."""
@@ -10,10 +10,10 @@ SRC = r'''
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
-static float div6(float x){ const float c = 0x1.555556p-3f; float q = x*c; float r = fmaf(-6.0f,q,x); return fmaf(r,c,q); }
+static float div6(float x){ const float c_hi = 0x1.555556p-3f, c_lo = -0x1.555556p-28f; return fmaf(x, c_hi, x*c_lo); }
 int main(void){
   long bad = 0, n = 0;
-  int exps[] = {-60, -10, -1, 0, 1, 2, 3, 7, 40};
+  int exps[] = {-100, -60, -10, -1, 0, 1, 2, 3, 7, 40, 100};
   for (unsigned e = 0; e < sizeof(exps)/sizeof(exps[0]); ++e)
     for (uint32_t m = 0; m < (1u<<23); ++m) {
       uint32_t bits = ((uint32_t)(127 + exps[e]) << 23) | m; float x; memcpy(&x,&bits,4);
