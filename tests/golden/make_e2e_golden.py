@@ -53,9 +53,7 @@ def main():
     print("md5 of this evaluation:", md5, " reference baseline:", baseline)
     np.savez_compressed(os.path.join(HERE, "e2e_ref.npz"), final=img, md5=md5, baseline_md5=baseline,
                         sky_sha256=keep["sky_sha256"], disk_tex=r.disk_texture_field.to_numpy(),
-                        stats=r._param_stats_field.to_numpy(), row_stats=r._param_row_stats_field.to_numpy(),
-                        bg=r.image_field.to_numpy(), blur=r.blur_field.to_numpy(),
-                        comp_bg_planes=r._comp_field.to_numpy()[[0, 3, 11, 12]].astype(np.float16))
+                        stats=r._param_stats_field.to_numpy(), row_stats=r._param_row_stats_field.to_numpy())
 
 
 if __name__ == "__main__":

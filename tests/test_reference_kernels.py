@@ -233,3 +233,32 @@ def test_tint_on_the_reference_s_own_calls(mode, texg, oracle):
     out = oracle.probe_tint(calls[:, 0], fast=("f64" if mode == "f64" else False))
     assert np.abs(out - calls[:, 1:4]).max() <= (2e-6 if mode == "f32" else 1e-6)
     assert calls[:, 0].min() < 6600 < calls[:, 0].max()   # both branches of the 66-hundred-kelvin split
+
+
+# --------------------------------------------------------------------------- the reference's e2e frame
+def load_e2e():
+    """tests/golden/e2e_ref.npz: the reference's own `render_image` on its tests/e2e_render.py scene (320x180),
+    every Taichi kernel of the pipeline executed as binary32 Python (make_e2e_golden.py).  -> fixture, sky."""
+    import hashlib as _h
+    from bhr_amd.skybox import generate_skybox
+    g = np.load(os.path.join(GOLD, "e2e_ref.npz"))
+    sky = generate_skybox(2048, 1024, seed=42, n_stars=100)
+    assert _h.sha256(np.ascontiguousarray(sky).tobytes()).hexdigest() == str(g["sky_sha256"]), \
+        "host skybox generator no longer reproduces the reference's sky"
+    return g, sky
+
+
+E2E_KW = dict(step_size=0.1, r_max=10, r_disk_inner=2.0, r_disk_outer=3.5, disk_tilt=15, anti_alias="disabled")
+
+
+def test_e2e_frame_march_and_bloom_on_the_reference_s_texture(oracle):
+    """The oracle's march + bloom on the texture and sky the reference's pipeline produced, against the frame the
+    reference's render() returned.  (Its MD5 differs from tests/e2e_baseline.txt, as it must: that hash belongs to
+    the author's LLVM fast-math build and carries no values; both are recorded in the fixture.)"""
+    g, sky = load_e2e()
+    assert str(g["md5"]) != str(g["baseline_md5"]) and len(str(g["baseline_md5"])) == 32
+    o = oracle.OracleRenderer(320, 180, sky, g["disk_tex"], **E2E_KW)
+    out = o.render([6, 0, 0.5], 60)
+    d = np.abs(out.astype(np.float64) - g["final"])
+    assert d.max() <= 2e-5 and np.sqrt((d ** 2).mean()) <= 5e-7, (d.max(), np.sqrt((d ** 2).mean()))
+    assert g["final"].max() > 0.5 and g["disk_tex"][..., 3].max() > 0.5
