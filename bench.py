@@ -13,6 +13,9 @@ ONE JSON line.
             step_size 0.1, disk 2-15, tilt 0, AA off), procedural disk texture + skybox;
 * N > 1     the path shards by independent frames (configs[4], frames f % N == rank): every
             rank renders its own fhd frames, no data-path collective => "scaling": "weak";
+            the row-block partition of ONE frame (configs[3], 8k in N blocks, halo exchange + gather with
+            hipMemcpyPeerAsync) is timed at every N as well and reported as `tile_scaling` (strong scaling);
+            `--workload 8k --gpus N` (or --strong) makes that leg the headline;
 * value     total ray-steps of all ranks / max-over-ranks wall time of the K timed steps.
 """
 import argparse
@@ -55,6 +58,10 @@ def parse():
     ap.add_argument("--no-other-math", action="store_true", help="skip the informational A/B leg (profiling)")
     ap.add_argument("--frame-slots", type=int, default=None, choices=[1, 2],
                     help="frames in flight per context (default 2: successive frames overlap on two streams)")
+    ap.add_argument("--strong", action="store_true",
+                    help="headline = ONE frame of --workload in --gpus row blocks (strong scaling; default for --workload 8k with N > 1)")
+    ap.add_argument("--tile-workload", default="8k", choices=sorted(WORKLOADS) + ["none"],
+                    help="frame of the row-block (strong-scaling) leg reported beside the headline; 'none' skips it")
     ap.add_argument("--math", default=None, choices=["fast", "strict"], help="march arithmetic (default: the renderer's)")
     return ap.parse_args()
 
@@ -99,6 +106,39 @@ def cpu_baseline(wl, sky, tex):
             "march_only_skip_diff_mray_steps_per_s": steps / t_skip / 1e6}
 
 
+def tile_leg(wl, n, frames, math=None, warmup=3):
+    """BASELINE.json configs[3]: ONE frame of ``wl`` cut into n cost-balanced row blocks, block k on device k.  Rank 0
+    drives all n devices from this process through bhr_group_render: every tile marches and H-blurs its rows
+    concurrently, neighbours exchange the bloom halo rows and every tile pushes its final rows to device 0 with
+    hipMemcpyPeerAsync (xGMI, no collective).  Strong scaling: the frame is fixed, n varies."""
+    from bhr_amd import _lib, multigpu, workloads
+    have = int(_lib.load().bhr_device_count())
+    if have < n:
+        return {"skipped": f"this process sees {have} HIP device(s), the leg needs {n}"}
+    tiles, blocks, note = workloads.make_tiles(wl, list(range(n)), math=math)
+    try:
+        for _ in range(max(warmup, 1)):
+            multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer")
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer")   # synchronises every tile's stream
+        el = time.perf_counter() - t0
+        cs = [t.counters() for t in tiles]
+        steps = sum(c["ray_steps"] for c in cs)
+        return {"metric": "Mray-steps/s", "value": steps * frames / el / 1e6, "unit": "Mray-steps/s", "scaling": "strong",
+                "n_gpus": n, "frames": frames, "ms_per_frame": el / frames * 1e3, "fps": frames / el,
+                "ray_steps_per_frame": int(steps),
+                "workload": f"{wl['width']}x{wl['height']} default scene, step_size {wl['step_size']}, one frame in {n} row blocks",
+                "row_blocks": [list(b) for b in blocks],
+                "tile_ms": {"march": [round(c["march_ms"], 3) for c in cs], "frame": [round(c["frame_ms"], 3) for c in cs]},
+                "exchange": "bloom halo rows + final gather onto device 0 with hipMemcpyPeerAsync, no collective",
+                "driven_by": "rank 0 drives all devices in one process (bhr_group_render); the other ranks wait at a host barrier",
+                "scene": note}
+    finally:
+        for t in tiles:
+            t.close()
+
+
 def main():
     args = parse()
     # Only the JSON line may reach stdout: RCCL prints a version banner there when NCCL_DEBUG is set, the scene
@@ -125,6 +165,31 @@ def main():
 
     from bhr_amd import workloads
     wl = WORKLOADS[args.workload]
+    if args.strong or (world > 1 and args.workload == "8k"):
+        # configs[3] as the headline: the frame is fixed, the devices share it in row blocks
+        D.host_barrier(dist)
+        if rank == 0:
+            t = tile_leg(wl, world, args.steps, math=args.math, warmup=args.warmup)
+            if "skipped" in t:
+                raise SystemExit("strong-scaling leg: " + t["skipped"])
+            slow = int(np.argmax(t["tile_ms"]["march"]))
+            px = (t["row_blocks"][slow][1] - t["row_blocks"][slow][0]) * wl["width"]
+            gbs = MARCH_BYTES_PER_PIXEL * px / (t["tile_ms"]["march"][slow] * 1e-3) / 1e9
+            out = {"metric": "Mray-steps/s", "value": t["value"], "unit": "Mray-steps/s", "fps": t["fps"], "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": t["ms_per_frame"], "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": args.workload + " " + t["workload"], "scene": t["scene"], "row_blocks": t["row_blocks"],
+                              "exchange": t["exchange"], "driven_by": t["driven_by"],
+                              "ray_steps_per_frame": t["ray_steps_per_frame"]},
+                   "kernel_ms": {"march_per_tile": t["tile_ms"]["march"], "frame_per_tile": t["tile_ms"]["frame"]},
+                   "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                "traffic": None, "kernel": f"march of the slowest tile (tile {slow})",
+                                "algorithmic_bytes_per_launch": MARCH_BYTES_PER_PIXEL * px}}
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        D.host_barrier(dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     renderer, sky, tex, scene_note = workloads.make_scene(wl, device_index=local_rank, math=args.math,
                                                           frame_slots=args.frame_slots)
 
@@ -189,6 +254,18 @@ def main():
     elapsed, total_steps = D.aggregate_throughput(elapsed, float(c["ray_steps_sum"]) if c["frames_timed"] == args.steps
                                                   else float(steps_per_frame) * args.steps, dist, device=red_dev)
 
+    # the row-block leg (configs[3]): reported beside the headline at every N, so that the per-N bench lines carry the
+    # tile-scaling curve as well as the frame-sharding one.  Every rank's GPU is idle while rank 0 times it.
+    tile = None
+    if args.tile_workload != "none" and not args.no_other_math:
+        D.host_barrier(dist)
+        if rank == 0:
+            try:
+                tile = tile_leg(WORKLOADS[args.tile_workload], world, max(args.steps // 10, 10), math=args.math)
+            except Exception as e:      # the headline stands on its own
+                tile = {"error": f"{type(e).__name__}: {e}"}
+        D.host_barrier(dist)
+
     if rank == 0:
         n_frames = c["frames_timed"]
         overlapped = {"march": c["march_ms_sum"] / max(n_frames, 1), "post": c["bloom_ms_sum"] / max(n_frames, 1),
@@ -243,6 +320,8 @@ def main():
           out["other_math"] = {"math": other, "value": co["ray_steps"] * n_other / el_other / 1e6, "unit": "Mray-steps/s",
                              "fps": n_other / el_other, "march_ms": co["march_ms_sum"] / max(co["frames_timed"], 1),
                              "note": "informational A/B in the same process; `value` above is the default (parity-certified) arithmetic"}
+        if tile is not None:
+            out["tile_scaling"] = tile
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, sky, tex)
         sys.stdout.flush()

@@ -13,7 +13,7 @@ from .build import library_path
 BHR_OK = 0
 BHR_ERR_INVALID, BHR_ERR_NO_DEVICE, BHR_ERR_HIP, BHR_ERR_STATE, BHR_ERR_NOMEM = -1, -2, -3, -4, -5
 
-SKIP_DIFFERENTIALS, SKIP_BLOOM, PERSISTENT, FORCE_FAST, FORCE_STRICT, LENS_FLARE, ROW_COSTS = 1, 2, 4, 8, 16, 32, 64
+SKIP_DIFFERENTIALS, SKIP_BLOOM, PERSISTENT, FORCE_FAST, FORCE_STRICT, LENS_FLARE, ROW_COSTS, GATHER_PEER = 1, 2, 4, 8, 16, 32, 64, 128
 MATH_FAST, MATH_STRICT = 0, 1
 LAYER_FINAL, LAYER_BG, LAYER_DISK, LAYER_BLUR = 0, 1, 2, 3
 
@@ -23,7 +23,7 @@ SYMBOLS = (
     "bhr_set_skybox", "bhr_skybox_add_glow", "bhr_get_skybox", "bhr_set_disk_texture", "bhr_get_disk_texture", "bhr_get_disk_mip", "bhr_num_mip_levels",
     "bhr_bg_init", "bhr_generate_background", "bhr_set_entity_staging", "bhr_set_comp", "bhr_read_comp",
     "bhr_fill_comp_slice", "bhr_set_compose_stats", "bhr_compose_texture", "bhr_eval_noise", "bhr_render",
-    "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_timing_reset", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities",
+    "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_timing_reset", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_read_gathered", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities",
     "bhr_stats_prepare", "bhr_stats_select", "bhr_stats_row_statistics",
     "bhr_png_bound", "bhr_png_encode", "bhr_png_write", "bhr_sink_create", "bhr_sink_submit", "bhr_sink_drain",
     "bhr_sink_destroy",
@@ -97,6 +97,7 @@ def load() -> C.CDLL:
     lib.bhr_eval_noise.argtypes = [P, F, C.c_int64, I32, I32, C.c_float, C.c_float, F]
     lib.bhr_render.argtypes = [P, C.POINTER(Camera), C.c_uint32]
     lib.bhr_read_layer.argtypes = [P, I32, F]
+    lib.bhr_read_gathered.argtypes = [P, F]
     lib.bhr_write_layer.argtypes = [P, I32, F]
     lib.bhr_bloom.argtypes = [P]
     lib.bhr_lens_flare.argtypes = [P]

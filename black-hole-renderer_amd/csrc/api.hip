@@ -285,7 +285,7 @@ void bhr_destroy(bhr_ctx *ctx) {
     void *bufs[] = {ctx->d_skybox,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_noise_in,
                     ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params, ctx->d_glow_hw, ctx->d_glow_wh,
-                    ctx->d_flare_c0, ctx->d_flare_c12, ctx->d_flare_prog, ctx->d_flare_sums, ctx->d_tile_order, ctx->d_row_steps};
+                    ctx->d_flare_c0, ctx->d_flare_c12, ctx->d_flare_prog, ctx->d_flare_sums, ctx->d_tile_order, ctx->d_row_steps, ctx->d_gather};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -593,6 +593,13 @@ int32_t bhr_lens_flare_sums(bhr_ctx *ctx, double *out3) {
     return download(ctx, out3, ctx->d_flare_sums, 3 * sizeof(double));
 }
 
+int32_t bhr_read_gathered(bhr_ctx *ctx, float *out) {
+    if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_read_gathered: bad argument");
+    if (!ctx->d_gather) return bhr_fail(BHR_ERR_STATE, "bhr_read_gathered: no bhr_group_render(..., BHR_GATHER_PEER) has gathered into this context");
+    BHR_TRY(use_device(ctx));
+    return download(ctx, out, ctx->d_gather, (size_t)ctx->cfg.height * ctx->cfg.width * 3 * sizeof(float));
+}
+
 int32_t bhr_read_final_u8(bhr_ctx *ctx, uint8_t *out) {
     if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_read_final_u8: bad argument");
     BHR_TRY(use_device(ctx));
@@ -778,7 +785,19 @@ int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint3
             BHR_HIP(hipEventRecord(ctxs[k]->ev[2], ctxs[k]->stream));
         }
     }
-    // phase 4: gather the final tiles -- every device copies into its own pinned buffer concurrently, the host
+    // phase 4a (BHR_GATHER_PEER): every tile pushes its final rows into the full-frame buffer on ctxs[0]'s device with
+    // hipMemcpyPeerAsync on its OWN stream -- n - 1 point-to-point xGMI links carry one tile each, concurrently
+    if (flags & BHR_GATHER_PEER) {
+        bhr_ctx *head = ctxs[0];
+        BHR_TRY(use_device(head));
+        if (!head->d_gather) BHR_TRY(dev_alloc(&head->d_gather, (size_t)H * W * 3));
+        for (int k = 0; k < n; ++k) {
+            BHR_TRY(use_device(ctxs[k]));
+            BHR_HIP(hipMemcpyPeerAsync(head->d_gather + (size_t)ctxs[k]->cfg.row0 * W * 3, head->cfg.device, ctxs[k]->d_final,
+                                       ctxs[k]->cfg.device, (size_t)ctxs[k]->rows * W * 3 * sizeof(float), ctxs[k]->stream));
+        }
+    }
+    // phase 4b: gather to the host -- every device copies into its own pinned buffer concurrently, the host
     // then assembles the frame (a pageable destination would serialise the eight DMA streams)
     if (out_host) {
         for (int k = 0; k < n; ++k) {

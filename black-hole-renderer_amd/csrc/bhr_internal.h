@@ -162,6 +162,7 @@ struct bhr_ctx {
     double *d_flare_c12;       // per chunk: sum x glow | sum y glow
     int32_t *d_flare_prog;     // pairwise tree of the ragged last chunk
     double *d_flare_sums;      // S0, S1, S2
+    float *d_gather;           // (H, W, 3): full frame gathered from the tiles of a group render (BHR_GATHER_PEER), on tile 0
     float *h_pinned;           // staging for readbacks
     size_t h_pinned_bytes;
 

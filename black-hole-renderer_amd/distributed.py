@@ -29,6 +29,24 @@ def init(backend: str, local_rank: int = 0):
     return dist
 
 
+_host_group = None
+
+
+def host_barrier(dist=None) -> None:
+    """Barrier that keeps the GPUs idle: a gloo group on the host cores.  An RCCL barrier is a small all-reduce
+    whose kernel spins on every waiting rank's GPU -- not what one wants while rank 0 times work on those GPUs
+    (bench.py's row-block leg)."""
+    global _host_group
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    if dist.get_backend() == "gloo":
+        dist.barrier()
+        return
+    if _host_group is None:
+        _host_group = dist.new_group(backend="gloo")
+    dist.barrier(group=_host_group)
+
+
 def aggregate_throughput(elapsed_s: float, units: float, dist=None, device="cpu") -> Tuple[float, float]:
     """Whole-job figures for weak scaling: (max over ranks of the elapsed time, sum over ranks of the
     units each rank processed).  Without a process group returns the inputs."""

@@ -80,18 +80,33 @@ def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
 
 
 def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_differentials=False,
-                 skip_bloom=False, lens_flare=False) -> np.ndarray:
+                 skip_bloom=False, lens_flare=False, gather: str = "host"):
     """Render one frame with the row-block renderers ``tiles`` (HipRenderer objects whose rows tile
-    the image in order).  Returns the gathered (H, W, 3) float32 frame."""
+    the image in order).  gather="host": returns the (H, W, 3) float32 frame, assembled from per-device pinned
+    buffers.  gather="peer": the tiles are gathered on tiles[0]'s device with hipMemcpyPeerAsync (xGMI) and stay
+    there -- returns None, read_gathered(tiles) fetches the frame (bench.py's strong-scaling leg times this one)."""
+    if gather not in ("host", "peer"):
+        raise ValueError(f"gather must be 'host' or 'peer', got {gather!r}")
     first = tiles[0]
     lib = _lib.load()
     arr = (C.c_void_p * len(tiles))(*[t._ctx for t in tiles])
-    out = np.empty((first.height, first.width, 3), dtype=np.float32)
     cam = first.camera_uniforms(cam_pos, fov, frame)
     flags = first._flags(skip_differentials, skip_bloom)
     if lens_flare:
         flags |= _lib.LENS_FLARE
+    if gather == "peer":
+        _lib.check(lib.bhr_group_render(arr, len(tiles), C.byref(cam), flags | _lib.GATHER_PEER, None))
+        return None
+    out = np.empty((first.height, first.width, 3), dtype=np.float32)
     _lib.check(lib.bhr_group_render(arr, len(tiles), C.byref(cam), flags, _lib.fptr(out)))
+    return out
+
+
+def read_gathered(tiles: Sequence) -> np.ndarray:
+    """The (H, W, 3) frame the last group_render(..., gather="peer") left on tiles[0]'s device."""
+    first = tiles[0]
+    out = np.empty((first.height, first.width, 3), dtype=np.float32)
+    _lib.check(_lib.load().bhr_read_gathered(first._ctx, _lib.fptr(out)))
     return out
 
 

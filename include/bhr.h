@@ -92,6 +92,8 @@ typedef struct {
 #define BHR_FORCE_STRICT      16u  /* this call only: strict arithmetic regardless of bhr_config.math_mode */
 #define BHR_ROW_COSTS         64u  /* also accumulate ray-steps per 8-row band (bhr_get_row_costs): the cost profile row blocks are balanced with */
 #define BHR_LENS_FLARE        32u  /* add the lens flare to the final layer on the device (render.py:3920-4028) */
+#define BHR_GATHER_PEER      128u  /* bhr_group_render: gather the tiles into one (H, W, 3) buffer on ctxs[0]'s device with
+                                      hipMemcpyPeerAsync (xGMI), one copy per tile on the tile's own stream */
 
 /* selectors for bhr_read_layer */
 typedef enum {
@@ -220,9 +222,12 @@ BHR_API int32_t bhr_get_row_costs(bhr_ctx *ctx, uint64_t *out, int32_t n);
  * ctxs[k] renders rows [row0_k,row1_k) of the same image; blocks must be
  * contiguous, ordered and cover [0,height).  Marches all tiles concurrently,
  * exchanges the R = int(0.02*W) H-blurred halo rows between neighbours with
- * hipMemcpyPeerAsync, runs the V pass per tile and gathers the final tiles
- * into ctxs[0] (device) and, if out_host != NULL, into out_host (H, W, 3). */
+ * hipMemcpyPeerAsync, runs the V pass per tile and gathers the final tiles:
+ * with BHR_GATHER_PEER into a full-frame buffer on ctxs[0]'s device (peer copies over xGMI, no collective),
+ * and, if out_host != NULL, into out_host (H, W, 3) through per-device pinned buffers.  Synchronises. */
 BHR_API int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host);
+/* The frame the last bhr_group_render(..., BHR_GATHER_PEER) gathered on this context's device: (H, W, 3) f32. */
+BHR_API int32_t bhr_read_gathered(bhr_ctx *ctx, float *out);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,9 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+# optional: --traffic <workload> <profiles/march_traffic.json> updates the per-launch HBM bytes of the march from the
+# FETCH_SIZE / WRITE_SIZE passes summarised here (no hand-typed numbers; bench.py reads the file into roofline.traffic)
+traffic_args = sys.argv[sys.argv.index("--traffic") + 1:sys.argv.index("--traffic") + 3] if "--traffic" in sys.argv else None
 
 
 def find(sub, suffix):
@@ -55,3 +58,31 @@ for sub in ("pmc_a", "pmc_b", "pmc_fetch", "pmc_write"):
         m = meta[k]
         print(f"| {k} | {m[0]}/{m[1]}/{m[2]} | {m[3]}x{m[4]} | " + " | ".join(row) + " |")
     print()
+
+
+if traffic_args:
+    import json
+    workload, path = traffic_args
+    vals = {}
+    for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        f = find(sub, "counter_collection.csv")
+        tot, n = defaultdict(float), defaultdict(int)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name and "march" in r["Kernel_Name"]:
+                k = short(r["Kernel_Name"])
+                tot[k] += float(r["Counter_Value"])
+                n[k] += 1
+        k = max(n, key=lambda q: tot[q])             # the dominant march instantiation of this workload
+        vals[name] = (k, tot[k] / n[k], n[k])
+    tj = json.load(open(path)) if os.path.isfile(path) else {}
+    tj[workload] = (vals["FETCH_SIZE"][1] + vals["WRITE_SIZE"][1]) * 1024.0
+    tj[f"_{workload}_detail"] = {"kernel": vals["FETCH_SIZE"][0], "FETCH_SIZE_KiB": vals["FETCH_SIZE"][1],
+                                 "WRITE_SIZE_KiB": vals["WRITE_SIZE"][1], "launches": vals["FETCH_SIZE"][2],
+                                 "profile": f"profiles/{os.path.basename(out).replace('prof_', '')}.md",
+                                 "commit": os.environ.get("BHR_COMMIT", "unknown")}
+    tj["source"] = "tools/summarize_prof.py from the pmc_fetch / pmc_write CSVs of tools/profile.sh; per workload: _<workload>_detail"
+    tj["_note"] = ("HBM bytes per march launch from rocprofv3 --pmc (separate passes): (FETCH_SIZE + WRITE_SIZE) KiB x 1024. "
+                   "WRITE_SIZE equals the two f32 framebuffers; FETCH_SIZE is uncalibrated for this kernel's 12-16 B gathers "
+                   "(MI355X_MICROARCH.md: the x2 correction applies to wide coalesced streams only) and is reported uncorrected.")
+    json.dump(tj, open(path, "w"), indent=1)
+    print(f"updated {path}: {workload} = {tj[workload]:.0f} B per launch", file=sys.stderr)
