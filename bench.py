@@ -113,9 +113,12 @@ def tile_leg(wl, n, frames, math=None, warmup=3):
     hipMemcpyPeerAsync (xGMI, no collective).  Strong scaling: the frame is fixed, n varies."""
     from bhr_amd import _lib, multigpu, workloads
     have = int(_lib.load().bhr_device_count())
-    if have < n:
-        return {"skipped": f"this process sees {have} HIP device(s), the leg needs {n}"}
-    tiles, blocks, note = workloads.make_tiles(wl, list(range(n)), math=math)
+    devices = list(range(n))
+    if os.environ.get("BHR_TILE_DEVICES"):               # e.g. "0,0": rehearse two tiles on one card
+        devices = [int(d) for d in os.environ["BHR_TILE_DEVICES"].split(",")]
+    if len(devices) != n or max(devices) >= have:
+        return {"skipped": f"this process sees {have} HIP device(s), the leg needs {n} (devices {devices})"}
+    tiles, blocks, note = workloads.make_tiles(wl, devices, math=math)
     try:
         for _ in range(max(warmup, 1)):
             multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer")

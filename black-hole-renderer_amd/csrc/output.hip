@@ -255,7 +255,186 @@ struct bhr_sink {
     }
 };
 
+// ---- YUV4MPEG2 stream ---------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int q8(float x) { return (int)(fminf(fmaxf(x, 0.0f), 1.0f) * 255.0f); }   // render.py:4463
+
+// One thread per 2x2 block: four luma samples, one Cb, one Cr.  FINAL is (h, w, 3) f32; out = Y (h*w) | Cb | Cr.
+__global__ void rgb_to_yuv420_kernel(const float *__restrict__ rgb, uint8_t *__restrict__ out, int w, int h) {
+    const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
+    const int cw = w >> 1, ch = h >> 1;
+    if (bx >= cw || by >= ch) return;
+    uint8_t *Y = out, *U = out + (size_t)w * h, *V = U + (size_t)cw * ch;
+    int sr = 0, sg = 0, sb = 0;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int x = 2 * bx + dx, y = 2 * by + dy;
+            const float *p = rgb + ((size_t)y * w + x) * 3;
+            const int r = q8(p[0]), g = q8(p[1]), b = q8(p[2]);
+            Y[(size_t)y * w + x] = (uint8_t)(((66 * r + 129 * g + 25 * b + 128) >> 8) + 16);
+            sr += r; sg += g; sb += b;
+        }
+    const int r = (sr + 2) >> 2, g = (sg + 2) >> 2, b = (sb + 2) >> 2;
+    U[(size_t)by * cw + bx] = (uint8_t)(((-38 * r - 74 * g + 112 * b + 128) >> 8) + 128);
+    V[(size_t)by * cw + bx] = (uint8_t)(((112 * r - 94 * g - 18 * b + 128) >> 8) + 128);
+}
+
+}  // namespace
+
+struct bhr_y4m {
+    bhr_ctx *ctx = nullptr;
+    int w = 0, h = 0;
+    size_t frame_bytes = 0;
+    FILE *f = nullptr;
+    uint8_t *d_yuv = nullptr;
+    struct Slot { uint8_t *host = nullptr; hipEvent_t ev = nullptr; };
+    std::vector<Slot> slots;
+    std::deque<int> free_slots, jobs;      // jobs in submission order: ONE writer keeps the frame order
+    int in_flight = 0;
+    bool stop = false;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_free, cv_idle;
+    std::thread writer;
+    int32_t err = BHR_OK;
+    std::string err_text;
+    int64_t frames = 0, bytes = 0;
+
+    void work() {
+        (void)hipSetDevice(ctx->cfg.device);
+        for (;;) {
+            int slot;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return stop || !jobs.empty(); });
+                if (jobs.empty()) return;
+                slot = jobs.front();
+                jobs.pop_front();
+            }
+            int32_t rc = BHR_OK;
+            const hipError_t e = hipEventSynchronize(slots[slot].ev);
+            if (e != hipSuccess) rc = bhr_fail(BHR_ERR_HIP, "y4m stream: hipEventSynchronize: %s", hipGetErrorString(e));
+            if (rc == BHR_OK && (fwrite("FRAME\n", 1, 6, f) != 6 || fwrite(slots[slot].host, 1, frame_bytes, f) != frame_bytes))
+                rc = bhr_fail(BHR_ERR_INVALID, "y4m stream: short write (reader gone?)");
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc != BHR_OK && err == BHR_OK) { err = rc; err_text = bhr_last_error(); }
+                if (rc == BHR_OK) { frames += 1; bytes += 6 + (int64_t)frame_bytes; }
+                free_slots.push_back(slot);
+                in_flight -= 1;
+            }
+            cv_free.notify_one();
+            cv_idle.notify_all();
+        }
+    }
+};
+
 extern "C" {
+
+int32_t bhr_y4m_open(bhr_ctx *ctx, const char *path, int32_t fps_num, int32_t fps_den, int32_t n_slots, bhr_y4m **out) {
+    if (!ctx || !path || !out || fps_num <= 0 || fps_den <= 0 || n_slots < 1 || n_slots > 256)
+        return bhr_fail(BHR_ERR_INVALID, "bhr_y4m_open: bad argument");
+    *out = nullptr;
+    if ((ctx->cfg.width & 1) || (ctx->rows & 1))
+        return bhr_fail(BHR_ERR_INVALID, "bhr_y4m_open: 4:2:0 needs even width and height, got %dx%d", ctx->cfg.width, ctx->rows);
+    BHR_TRY(bhr_enter(ctx));
+    bhr_y4m *s = new bhr_y4m();
+    s->ctx = ctx;
+    s->w = ctx->cfg.width;
+    s->h = ctx->rows;
+    s->frame_bytes = (size_t)s->w * s->h * 3 / 2;
+    s->f = fopen(path, "wb");
+    if (!s->f) { delete s; return bhr_fail(BHR_ERR_INVALID, "bhr_y4m_open: cannot open %s for writing", path); }
+    setvbuf(s->f, nullptr, _IOFBF, 1 << 22);
+    fprintf(s->f, "YUV4MPEG2 W%d H%d F%d:%d Ip A1:1 C420jpeg XCOLORRANGE=LIMITED\n", s->w, s->h, fps_num, fps_den);
+    hipError_t e = hipMalloc((void **)&s->d_yuv, s->frame_bytes);
+    s->slots.resize(n_slots);
+    for (int k = 0; k < n_slots && e == hipSuccess; ++k) {
+        e = hipHostMalloc((void **)&s->slots[k].host, s->frame_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->slots[k].ev, hipEventDisableTiming);
+        s->free_slots.push_back(k);
+    }
+    s->writer = std::thread(&bhr_y4m::work, s);
+    if (e != hipSuccess) {
+        bhr_y4m_close(s);
+        return bhr_fail(BHR_ERR_HIP, "bhr_y4m_open: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return BHR_OK;
+}
+
+int32_t bhr_y4m_submit(bhr_y4m *s) {
+    if (!s) return bhr_fail(BHR_ERR_INVALID, "bhr_y4m_submit: null stream");
+    int slot;
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        if (s->err != BHR_OK) return bhr_fail(s->err, "y4m stream: %s", s->err_text.c_str());
+        s->cv_free.wait(lk, [&] { return !s->free_slots.empty(); });
+        slot = s->free_slots.front();
+        s->free_slots.pop_front();
+        s->in_flight += 1;
+    }
+    bhr_ctx *ctx = s->ctx;
+    int32_t rc = bhr_enter(ctx);             // the scene stream follows the frame in flight
+    hipError_t e = hipSuccess;
+    if (rc == BHR_OK) {
+        dim3 block(32, 8), grid(((s->w >> 1) + 31) / 32, ((s->h >> 1) + 7) / 8);
+        hipLaunchKernelGGL(rgb_to_yuv420_kernel, grid, block, 0, ctx->stream, ctx->d_final, s->d_yuv, s->w, s->h);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(s->slots[slot].host, s->d_yuv, s->frame_bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(s->slots[slot].ev, ctx->stream);
+    }
+    if (e != hipSuccess || rc != BHR_OK) {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->free_slots.push_back(slot);
+        s->in_flight -= 1;
+        return e != hipSuccess ? bhr_fail(BHR_ERR_HIP, "bhr_y4m_submit: %s", hipGetErrorString(e)) : rc;
+    }
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->jobs.push_back(slot);
+    }
+    s->cv_job.notify_one();
+    return BHR_OK;
+}
+
+int32_t bhr_y4m_drain(bhr_y4m *s, int64_t *frames_written, int64_t *bytes_written) {
+    if (!s) return bhr_fail(BHR_ERR_INVALID, "bhr_y4m_drain: null stream");
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv_idle.wait(lk, [&] { return s->in_flight == 0; });
+    if (s->f) fflush(s->f);
+    if (frames_written) *frames_written = s->frames;
+    if (bytes_written) *bytes_written = s->bytes;
+    if (s->err != BHR_OK) {
+        const int32_t code = s->err;
+        const std::string text = s->err_text;
+        lk.unlock();
+        return bhr_fail(code, "y4m stream: %s", text.c_str());
+    }
+    return BHR_OK;
+}
+
+void bhr_y4m_close(bhr_y4m *s) {
+    if (!s) return;
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv_idle.wait(lk, [&] { return s->in_flight == 0; });
+        s->stop = true;
+    }
+    s->cv_job.notify_all();
+    if (s->writer.joinable()) s->writer.join();
+    if (s->f) fclose(s->f);
+    (void)hipSetDevice(s->ctx->cfg.device);
+    (void)hipStreamSynchronize(s->ctx->scene_stream);   // d_yuv may still be the source of the last copy
+    for (auto &sl : s->slots) {
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+        if (sl.host) (void)hipHostFree(sl.host);
+    }
+    if (s->d_yuv) (void)hipFree(s->d_yuv);
+    delete s;
+}
 
 int64_t bhr_png_bound(int32_t w, int32_t h) {
     if (w <= 0 || h <= 0) return 0;

@@ -21,7 +21,7 @@ import numpy as np
 
 from .camera import orbit_position
 from .lifecycle import make_factories
-from .output import FrameSink, VIDEO_LEVEL, png_write, quantize
+from .output import Y4MStream, FrameSink, VIDEO_LEVEL, png_write, quantize
 from .renderer import HipRenderer, R_DISK_INNER_DEFAULT, R_DISK_OUTER_DEFAULT
 from .skybox import load_or_generate_skybox
 from .textures import compute_disk_texture_resolution, load_disk_texture
@@ -169,8 +169,15 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
                  fov: float, static_cam_pos: List[float], orbit: bool = False, resume: bool = False,
                  disk_rotation_speed: float = 0.1, orbit_degrees: float = 360.0, rank: int = 0, world: int = 1,
                  assemble: bool = True, png_level: int = VIDEO_LEVEL, sink_slots: int = 0, sink_workers: int = 0,
-                 **_deprecated_kwargs) -> None:
-    """N frames -> PNGs (+ MP4) (render.py:4356-4511).  Frame f is rendered by rank f % world."""
+                 video_stream: str = "auto", **_deprecated_kwargs) -> None:
+    """N frames -> PNGs (+ MP4) (render.py:4356-4511).  Frame f is rendered by rank f % world.
+
+    ``video_stream``: the reference assembles the MP4 by reading every PNG back (render.py:4497-4503).  Here a
+    single-rank, non-resumed session can also hand the frames straight to the encoder as a yuv420p YUV4MPEG2
+    stream converted on the device (output.Y4MStream): "auto" pipes it into ``ffmpeg -f yuv4mpegpipe`` when an
+    ffmpeg binary is on PATH (MP4 written while the frames render; otherwise PNGs + assemble_video as before),
+    "y4m" writes ``<output stem>.y4m`` beside the output, "off" never streams.  PNG frames and progress.json are
+    written in every mode (resume format of the reference)."""
     os.makedirs(os.path.dirname(output_path) or ".", exist_ok=True)
     temp_dir = _frames_dir(output_path)
     submitted: List[int] = []
@@ -178,27 +185,54 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
     params = {"n_frames": n_frames, "fov": fov, "orbit": orbit, "disk_rotation_speed": disk_rotation_speed,
               "orbit_degrees": orbit_degrees}
 
+    # Resume (render.py:4380-4434).  With several ranks the decision to start over is taken ONCE: every rank looks
+    # at the same merged record of all ranks' progress files, only frame files and progress files are removed (never
+    # the directory another rank may be creating or writing into), and each rank removes only what belongs to it.
     completed = set()
-    if resume and os.path.isdir(temp_dir) and os.path.isfile(progress_file):
-        with open(progress_file) as f:
-            saved = json.load(f)
-        if saved.get("params", {}) != params:
+    os.makedirs(temp_dir, exist_ok=True)
+    if resume:
+        records = []
+        for name in sorted(os.listdir(temp_dir)):
+            if name == "progress.json" or (name.startswith("progress.rank") and name.endswith(".json")):
+                try:
+                    with open(os.path.join(temp_dir, name)) as f:
+                        records.append(json.load(f))
+                except (OSError, ValueError):
+                    pass
+        if records and any(r.get("params", {}) != params for r in records):
             print("Warning: parameters changed, starting over")
-            if rank == 0:
-                shutil.rmtree(temp_dir)
-            os.makedirs(temp_dir, exist_ok=True)
-        else:
-            completed = {f for f in saved.get("completed", [])
-                         if os.path.isfile(os.path.join(temp_dir, f"frame_{f:04d}.png"))}
+            for fr in range(rank, n_frames, world):                  # this rank's own frames
+                try:
+                    os.remove(os.path.join(temp_dir, f"frame_{fr:04d}.png"))
+                except OSError:
+                    pass
+            try:
+                os.remove(progress_file)
+            except OSError:
+                pass
+        elif records:
+            done = set()
+            for r in records:                                        # a different world size last time: still counted
+                done |= set(r.get("completed", []))
+            completed = {f for f in done if os.path.isfile(os.path.join(temp_dir, f"frame_{f:04d}.png"))}
             print(f"Resuming: {len(completed)}/{n_frames} frames already rendered")
-    else:
-        os.makedirs(temp_dir, exist_ok=True)
 
     total_t0 = time.time()
     rendered = 0
     # the reference saves through a 2-thread PIL pool (render.py:4412-4413); here the frame is quantised
     # on the device, copied into a pinned ring and encoded by worker threads while the next frames render
     sink = FrameSink(renderer, slots=sink_slots, workers=sink_workers, level=png_level)
+    if video_stream not in ("auto", "y4m", "off"):
+        raise ValueError(f"video_stream must be 'auto', 'y4m' or 'off', got {video_stream!r}")
+    stream = encoder = None
+    streamable = world == 1 and not completed and width % 2 == 0 and height % 2 == 0
+    if streamable and video_stream == "y4m":
+        stream = Y4MStream(renderer, os.path.splitext(output_path)[0] + ".y4m", fps)
+    elif streamable and video_stream == "auto" and assemble and shutil.which("ffmpeg"):
+        import subprocess
+        encoder = subprocess.Popen(["ffmpeg", "-y", "-loglevel", "error", "-f", "yuv4mpegpipe", "-i", "-", "-c:v", "libx264",
+                                    "-pix_fmt", "yuv420p", output_path], stdin=subprocess.PIPE)
+        stream = Y4MStream(renderer, f"/proc/self/fd/{encoder.stdin.fileno()}", fps)
 
     n_r, n_phi = renderer.dtex_h, renderer.dtex_w
     factories = init_lifecycle_system(renderer, n_r, n_phi, seed=42)
@@ -217,6 +251,8 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
         t0 = time.time()
         renderer.render_async(cam_pos, fov, frame=0)   # lens flare, when enabled, is applied on the device
         sink.submit(os.path.join(temp_dir, f"frame_{frame:04d}.png"))
+        if stream is not None:
+            stream.submit()
         elapsed = time.time() - t0
         rendered += 1
         submitted.append(frame)
@@ -231,6 +267,17 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
 
     frames_written, bytes_written = sink.drain()
     sink.close()
+    streamed = False
+    if stream is not None:
+        n_streamed, _ = stream.drain()
+        stream.close()
+        if encoder is not None:
+            encoder.stdin.close()
+            streamed = encoder.wait() == 0 and n_streamed == n_frames
+            print(f"Video saved: {output_path} (yuv420p stream, {n_streamed} frames)" if streamed
+                  else "ffmpeg failed on the stream; falling back to the PNG frames")
+        else:
+            print(f"YUV4MPEG2 stream: {os.path.splitext(output_path)[0]}.y4m ({n_streamed} frames)")
     completed.update(submitted)
     with open(progress_file, "w") as f:
         json.dump({"params": params, "completed": sorted(completed)}, f)
@@ -243,4 +290,5 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
     if len(completed) < n_frames:
         print(f"Warning: only {len(completed)}/{n_frames} frames completed. Run again to resume.")
         return
-    assemble_video(temp_dir, n_frames, fps, output_path)
+    if not streamed:
+        assemble_video(temp_dir, n_frames, fps, output_path)

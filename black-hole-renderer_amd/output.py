@@ -99,3 +99,79 @@ class FrameSink:
             self.close()
         except Exception:
             pass
+
+
+def rgb_to_yuv420(rgb_u8: np.ndarray):
+    """The stream's colour conversion on the host (checker for the device kernel; integer BT.601 limited range,
+    chroma from the rounded mean of each 2x2 block): (H, W, 3) uint8 -> (Y (H, W), Cb (H/2, W/2), Cr (H/2, W/2))."""
+    a = _u8(rgb_u8).astype(np.int32)
+    r, g, b = a[..., 0], a[..., 1], a[..., 2]
+    y = ((66 * r + 129 * g + 25 * b + 128) >> 8) + 16
+    h, w = r.shape
+    m = (a.reshape(h // 2, 2, w // 2, 2, 3).sum(axis=(1, 3)) + 2) >> 2
+    r, g, b = m[..., 0], m[..., 1], m[..., 2]
+    cb = ((-38 * r - 74 * g + 112 * b + 128) >> 8) + 128
+    cr = ((112 * r - 94 * g - 18 * b + 128) >> 8) + 128
+    return y.astype(np.uint8), cb.astype(np.uint8), cr.astype(np.uint8)
+
+
+def read_y4m(path: str):
+    """Minimal YUV4MPEG2 reader (4:2:0): -> (header dict, list of (Y, Cb, Cr) uint8 planes)."""
+    with open(path, "rb") as f:
+        head = f.readline().decode("ascii").split()
+        assert head[0] == "YUV4MPEG2", head
+        tags = {t[0]: t[1:] for t in head[1:]}
+        w, h = int(tags["W"]), int(tags["H"])
+        frames = []
+        while True:
+            line = f.readline()
+            if not line:
+                break
+            assert line.startswith(b"FRAME"), line[:20]
+            buf = np.frombuffer(f.read(w * h * 3 // 2), dtype=np.uint8)
+            assert buf.size == w * h * 3 // 2, "truncated frame"
+            frames.append((buf[:w * h].reshape(h, w), buf[w * h:w * h * 5 // 4].reshape(h // 2, w // 2),
+                           buf[w * h * 5 // 4:].reshape(h // 2, w // 2)))
+    return {"width": w, "height": h, "fps": tags["F"], "chroma": [t for t in head[1:] if t.startswith("C")][0],
+            "tags": head[1:]}, frames
+
+
+class Y4MStream:
+    """Device frames -> one YUV4MPEG2 (yuv420p) stream, in submission order, without a PNG detour
+    (replaces the PNG -> imread -> libx264 assembly of render.py:4497-4503; include/bhr_output.h)."""
+
+    def __init__(self, renderer, path: str, fps: int, slots: int = 8):
+        self._lib = _lib.load()
+        self._s = C.c_void_p()
+        self._renderer = renderer
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        _lib.check(self._lib.bhr_y4m_open(renderer._ctx, os.fsencode(path), int(fps), 1, slots, C.byref(self._s)))
+        import weakref
+        if not hasattr(renderer, "_sinks"):
+            renderer._sinks = []
+        renderer._sinks.append(weakref.ref(self))
+
+    def submit(self) -> None:
+        _lib.check(self._lib.bhr_y4m_submit(self._s))
+
+    def drain(self):
+        frames, nbytes = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.bhr_y4m_drain(self._s, C.byref(frames), C.byref(nbytes)))
+        return frames.value, nbytes.value
+
+    def close(self) -> None:
+        if self._s:
+            self._lib.bhr_y4m_close(self._s)
+            self._s = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

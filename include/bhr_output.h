@@ -35,6 +35,25 @@ BHR_API int32_t bhr_sink_submit(bhr_sink *sink, const char *path);
 BHR_API int32_t bhr_sink_drain(bhr_sink *sink, int64_t *frames_written, int64_t *bytes_written);
 BHR_API void bhr_sink_destroy(bhr_sink *sink);
 
+/* Video stream without the PNG detour (replaces render.py:4497-4503, where the reference re-reads every PNG and
+ * feeds libx264 through imageio/pyav with pixelformat yuv420p).  bhr_y4m_submit converts the context's FINAL layer
+ * on the device -- the reference's u8 quantisation (render.py:4463), then BT.601 limited-range Y'CbCr with the
+ * chroma of each 2x2 block taken from its rounded mean RGB (4:2:0, centre sited) -- copies the 1.5 bytes/pixel
+ * asynchronously into a pinned ring and returns; ONE writer thread appends the frames in submission order to
+ * `path` as YUV4MPEG2 ("YUV4MPEG2 W.. H.. F<num>:<den> Ip A1:1 C420jpeg XCOLORRANGE=LIMITED", then "FRAME\n" + Y, Cb, Cr
+ * planes per frame).  `path` may be a FIFO or "-"-less file path; `ffmpeg -f yuv4mpegpipe -i path -c:v libx264 -pix_fmt
+ * yuv420p out.mp4` turns it into the reference's MP4 (drivers.render_video does that when an ffmpeg binary exists).
+ * Width and height must be even.  Integer arithmetic (exactly reproducible on the host):
+ *   Y  = ((66 R + 129 G + 25 B + 128) >> 8) + 16,  Cb = ((-38 R - 74 G + 112 B + 128) >> 8) + 128,
+ *   Cr = ((112 R - 94 G - 18 B + 128) >> 8) + 128,  chroma R,G,B = (sum of the 2x2 block + 2) >> 2. */
+typedef struct bhr_y4m bhr_y4m;
+BHR_API int32_t bhr_y4m_open(bhr_ctx *ctx, const char *path, int32_t fps_num, int32_t fps_den, int32_t slots, bhr_y4m **out);
+BHR_API int32_t bhr_y4m_submit(bhr_y4m *stream);
+/* Wait until every submitted frame has been written; first writer error, if any.  frames_written may be NULL. */
+BHR_API int32_t bhr_y4m_drain(bhr_y4m *stream, int64_t *frames_written, int64_t *bytes_written);
+/* Drains, closes the file and frees the stream. */
+BHR_API void bhr_y4m_close(bhr_y4m *stream);
+
 #ifdef __cplusplus
 }
 #endif

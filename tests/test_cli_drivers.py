@@ -237,6 +237,31 @@ def test_bench_two_ranks_rehearsal():
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("strong", [False, True])
+def test_bench_row_block_leg_rehearsal(strong):
+    """The strong-scaling leg of bench.py under torchrun: rank 0 drives one context per tile (both tiles on the one
+    card here, BHR_TILE_DEVICES), the other rank waits at the host barrier; as `tile_scaling` beside the weak
+    headline, and as the headline itself with --strong."""
+    import json
+    env = dict(os.environ, BHR_DIST_BACKEND="gloo", BHR_FORCE_DEVICE="0", BHR_TILE_DEVICES="0,0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29535" if strong else "29536", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "20", "--warmup", "3", "--workload", "sd", "--tile-workload", "sd", "--no-cpu-baseline"]
+    p = subprocess.run(cmd + (["--strong"] if strong else []), capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    t = d if strong else d["tile_scaling"]
+    assert d["n_gpus"] == 2 and d["scaling"] == ("strong" if strong else "weak")
+    assert t["scaling"] == "strong" and t["n_gpus"] == 2 and t["value"] > 0
+    blocks = (d["config"] if strong else t)["row_blocks"]
+    assert len(blocks) == 2 and blocks[0][0] == 0 and blocks[1][1] == 360 and blocks[0][1] == blocks[1][0]
+    if strong:
+        assert d["steps"] == 20 and abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 / d["config"]["ray_steps_per_frame"] - 1) < 1e-6
+
+
 def test_balanced_row_blocks_properties():
     from bhr_amd.multigpu import balanced_row_blocks, row_blocks
     rng = np.random.default_rng(0)

@@ -41,6 +41,7 @@ def _worker(rank, world, port, tmp):
     with open(os.path.join(tmp, f"progress.rank{rank}.json"), "w") as f:
         json.dump({"params": {}, "completed": mine}, f)
     d.barrier()
+    D.host_barrier(d)                       # bench.py's GPU-idle barrier (gloo group beside the data backend)
     if rank == 0:
         assert D.merge_progress(tmp, world) == set(range(37))
     d.barrier()

@@ -68,10 +68,10 @@ def test_make_tiles_cost_balanced_blocks(hip_lib):
     tiles, blocks, _ = workloads.make_tiles(wl, [0, 0, 0], n_stars=200)
     assert blocks[0][0] == 0 and blocks[-1][1] == 360 and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
     assert all(b[0] % 8 == 0 for b in blocks)
-    sizes = [b[1] - b[0] for b in blocks]
-    assert sizes[1] < sizes[0] and sizes[1] < sizes[2]        # the rows through the shadow cost more: a thinner block
     multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer")
     got = multigpu.read_gathered(tiles)
+    steps = np.array([t.counters()["ray_steps"] for t in tiles], dtype=np.float64)
+    assert steps.max() / steps.mean() <= 1.10, steps            # the cut is by cost: no tile marches 10 % more than the mean
     one, _, _, _ = workloads.make_scene(wl, n_stars=200)
     np.testing.assert_allclose(got, one.render(wl["cam_pos"], wl["fov"]), atol=1e-6, rtol=0)
     for t in tiles + [one]:
