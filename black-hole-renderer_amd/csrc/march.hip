@@ -980,8 +980,11 @@ __global__ __launch_bounds__(256) void march_persistent_kernel(BhrMarchArgs a, i
     const int lane = threadIdx.x & 63;
     const unsigned int total = (unsigned int)a.n_tiles * 64u;
     Ray<DIFF> ray;
-    ray.done = 4;  // empty lane
+    ray.done = 4;  // empty lane: no pixel, nothing parked, nothing accumulated
     ray.pix = -1;
+    ray.n_pend = 0;
+    ray.sh.accum = mk(0, 0, 0);
+    ray.sh.alpha_total = 0.0f;
     unsigned int executed = 0;
     bool queue_empty = false;
 
@@ -1005,6 +1008,7 @@ __global__ __launch_bounds__(256) void march_persistent_kernel(BhrMarchArgs a, i
             if ((want >> lane) & 1ull) {   // running lanes keep their ray
                 ray.done = 4;
                 ray.pix = -1;
+                ray.n_pend = 0;       // a lane that gets no pixel (queue exhausted) must not look as if it had a hit parked
                 int i, j;
                 if (w < total && tile_pixel(a, w, i, j)) ray.init(a, i, j);
             }

@@ -4,8 +4,8 @@ The host keeps what is cheap and order-sensitive -- the factories' random stream
 scalars, the per-(entity, row) scalars that depend on NumPy's promotion rules -- and hands the
 per-texel work to the GPU: ~12 000 (entity, row) pairs instead of 6 x n_r x n_phi texels cross
 PCIe per frame, and the percentile statistics are selected on the device without reading the 13
-component planes back.  `lifecycle.rasterize_entities` / `compose_statistics` remain the
-reference-identical host implementations these are tested against.
+component planes back.  tests/lifecycle_checker.py holds the reference-identical NumPy forms these are
+tested against.
 """
 from __future__ import annotations
 
@@ -15,7 +15,7 @@ import math
 import numpy as np
 
 from . import _lib
-from .lifecycle import (FILAMENT_BIRTH_FADE_DUR, FILAMENT_DEATH_THRESHOLD)
+from .lifecycle import FILAMENT_BIRTH_FADE_DUR, FILAMENT_DEATH_THRESHOLD, envelope, filament_strength
 
 FIL_DTYPE = np.dtype([("center", "<f8"), ("inv_2s_phi", "<f8"), ("coef_d", "<f8"), ("coef_t", "<f8")])
 ROL_DTYPE = np.dtype([("offset", "<i8"), ("shift", "<i4"), ("plane", "<i4"), ("alpha", "<f4"), ("stride", "<i4")])
@@ -47,9 +47,9 @@ def _filament_static(e, n_r: int, omega_rows: np.ndarray, r_norm_all: np.ndarray
     c = getattr(e, "_pair_static", None)
     if c is None or c[0] != n_r:
         rows = e.row_indices[(e.row_indices >= 0) & (e.row_indices < n_r)].astype(np.int64)
-        sigma_r = max(e.blob_sigma_r, 1e-6)
+        sigma_r = max(e.sigma_r, 1e-6)
         inv_2s_r = 0.5 / (sigma_r * sigma_r)
-        r_w = np.array([math.exp(-(r_norm_all[ri] - e.blob_base_r) ** 2 * inv_2s_r) for ri in rows], dtype=np.float64)
+        r_w = np.array([math.exp(-(r_norm_all[ri] - e.base_r) ** 2 * inv_2s_r) for ri in rows], dtype=np.float64)
         c = (n_r, rows, r_w, omega_rows[rows])
         e._pair_static = c
     return c
@@ -57,24 +57,24 @@ def _filament_static(e, n_r: int, omega_rows: np.ndarray, r_norm_all: np.ndarray
 
 def filament_pairs(factory, now: float, n_r: int, omega_rows: np.ndarray, r_norm_all: np.ndarray):
     """(rows, table) for the alive filaments in list order (render.py:3606-3638).  The per-row
-    scalars are evaluated exactly as `lifecycle.rasterize_entities` does (f32 centre under NumPy's
+    scalars are evaluated exactly as the reference's NumPy rasteriser does (f32 centre under NumPy's
     weak-scalar promotion, f64 radial weight through math.exp); the per-entity scalars are computed
     in a Python loop, everything per (entity, row) in one vector pass over all pairs."""
     rows_l, rw_l, om_l, counts = [], [], [], []
     src, age32, inv2s, sc_d, sc_t = [], [], [], [], []
     for e in factory.alive_entities:
         age = now - e.birth_time
-        if e.density_factor(age) < FILAMENT_DEATH_THRESHOLD:
+        if filament_strength(e, age) < FILAMENT_DEATH_THRESHOLD:
             continue
         _, rows, r_w, om = _filament_static(e, n_r, omega_rows, r_norm_all)
         if len(rows) == 0:
             continue
-        s0 = max(e.blob_sigma_phi0, 1e-6)
-        sigma_phi = s0 + e.alpha_shear * age
-        amp_d = e.blob_peak_density * s0 / sigma_phi
-        amp_t = e.blob_peak_temp * s0 / sigma_phi
+        s0 = max(e.sigma_phi0, 1e-6)
+        sigma_phi = s0 + e.shear_rate * age
+        amp_d = e.peak_density * s0 / sigma_phi
+        amp_t = e.peak_temp * s0 / sigma_phi
         born = min(age / FILAMENT_BIRTH_FADE_DUR, 1.0) if FILAMENT_BIRTH_FADE_DUR > 0 else 1.0
-        cool = math.exp(-age / e.tau_cool) if e.tau_cool > 0 else 1.0
+        cool = math.exp(-age / e.cooling_time) if e.cooling_time > 0 else 1.0
         rows_l.append(rows); rw_l.append(r_w); om_l.append(om); counts.append(len(rows))
         src.append(e.source_phi); age32.append(age)
         inv2s.append(0.5 / (sigma_phi * sigma_phi))
@@ -106,7 +106,7 @@ def rolled_pairs(factories: dict, now: float, n_r: int, n_phi: int, omega_rows: 
         if factory is None:
             continue
         for e in factory.alive_entities:
-            alpha = e.fade_factor(now)
+            alpha = envelope(e, now)
             if alpha <= 0:
                 continue
             off, stride = pool.offset_of(e)

@@ -259,34 +259,22 @@ class HipRenderer:
         _lib.check(self._lib.bhr_read_comp(self._ctx, _lib.fptr(out)))
         return out
 
-    # The entity layer and the statistics run on the device by default (lifecycle_device.py);
-    # device_lifecycle = False selects the reference-identical NumPy implementations + upload,
-    # which the GPU tests compare against.
-    device_lifecycle = True
-
     def accumulate_entity_layer(self, factories: dict, now: float) -> None:
-        """Rasterise the alive entities into comp[5:11] (render.py:3564-3653)."""
-        if self.device_lifecycle:
-            from . import lifecycle_device as ld
-            if getattr(self, "_profile_pool", None) is None:
-                self._profile_pool = ld.ProfilePool(self._lib, self._ctx, self._bg_n_phi)
-            ld.accumulate_on_device(self._lib, self._ctx, self._profile_pool, factories, now, self._bg_n_r,
-                                    self._bg_n_phi, self._bg_omega_all_np, self._bg_r_norm_all)
-            return
-        from .lifecycle import rasterize_entities
-        staging = rasterize_entities(factories, now, self._bg_n_r, self._bg_n_phi, self._bg_omega_all_np,
-                                     self._bg_r_norm_all)
-        _lib.check(self._lib.bhr_set_entity_staging(self._ctx, _lib.fptr(staging)))
+        """Rasterise the alive entities into comp[5:11] on the device (render.py:3564-3653): the host sends
+        (entity, row) pair tables, csrc/lifecycle.hip does the per-texel work."""
+        from . import lifecycle_device as ld
+        if getattr(self, "_profile_pool", None) is None:
+            self._profile_pool = ld.ProfilePool(self._lib, self._ctx, self._bg_n_phi)
+        ld.accumulate_on_device(self._lib, self._ctx, self._profile_pool, factories, now, self._bg_n_r,
+                                self._bg_n_phi, self._bg_omega_all_np, self._bg_r_norm_all)
 
     def recompute_interactive_stats(self) -> None:
-        """Normalisation statistics from the current components (render.py:3655-3712)."""
-        if self.device_lifecycle and self._bg_n_phi <= 32768:
-            from . import lifecycle_device as ld
-            p98, scale, row_stats = ld.stats_on_device(self._lib, self._ctx, self._bg_n_r, self._bg_n_phi,
-                                                       self._param_enable_rt)
-        else:
-            from .lifecycle import compose_statistics
-            p98, scale, row_stats = compose_statistics(self.read_comp(), self._edge_np, self._param_enable_rt)
+        """Normalisation statistics from the current components, selected on the device (render.py:3655-3712)."""
+        if self._bg_n_phi > 32768:
+            raise ValueError(f"device statistics support textures up to 32768 columns, got {self._bg_n_phi}")
+        from . import lifecycle_device as ld
+        p98, scale, row_stats = ld.stats_on_device(self._lib, self._ctx, self._bg_n_r, self._bg_n_phi,
+                                                   self._param_enable_rt)
         self._set_stats(p98, scale, row_stats)
 
     def compose_interactive_texture(self, solo_idx: int = -1) -> None:

@@ -52,7 +52,7 @@ def test_no_cpu_fallback_without_device(hip_lib):
     from bhr_amd import _lib
     if hip_lib.bhr_device_count() > 0:
         pytest.skip("a GPU is present")
-    cfg = _lib.Config(64, 36, 0, 36, 0.1, 10.0, 2.0, 15.0, 0.0, 0, 1.0, 0.1, 0)
+    cfg = _lib.Config(64, 36, 0, 36, 0.1, 10.0, 2.0, 15.0, 0.0, 0, 1.0, 0.1, 0, _lib.MATH_STRICT)
     h = C.c_void_p()
     rc = hip_lib.bhr_create(C.byref(cfg), C.byref(h))
     assert rc == _lib.BHR_ERR_NO_DEVICE and not h.value
@@ -64,11 +64,11 @@ def test_no_cpu_fallback_without_device(hip_lib):
 def test_argument_validation_needs_no_device(hip_lib):
     from bhr_amd import _lib
     h = C.c_void_p()
-    bad = _lib.Config(0, 36, 0, 36, 0.1, 10.0, 2.0, 15.0, 0.0, 0, 1.0, 0.1, 0)
+    bad = _lib.Config(0, 36, 0, 36, 0.1, 10.0, 2.0, 15.0, 0.0, 0, 1.0, 0.1, 0, _lib.MATH_STRICT)
     assert hip_lib.bhr_create(C.byref(bad), C.byref(h)) == _lib.BHR_ERR_INVALID
-    bad = _lib.Config(64, 36, 10, 5, 0.1, 10.0, 2.0, 15.0, 0.0, 0, 1.0, 0.1, 0)
+    bad = _lib.Config(64, 36, 10, 5, 0.1, 10.0, 2.0, 15.0, 0.0, 0, 1.0, 0.1, 0, _lib.MATH_STRICT)
     assert hip_lib.bhr_create(C.byref(bad), C.byref(h)) == _lib.BHR_ERR_INVALID
-    bad = _lib.Config(64, 36, 0, 36, 0.1, 10.0, 5.0, 3.0, 0.0, 0, 1.0, 0.1, 0)
+    bad = _lib.Config(64, 36, 0, 36, 0.1, 10.0, 5.0, 3.0, 0.0, 0, 1.0, 0.1, 0, _lib.MATH_STRICT)
     assert hip_lib.bhr_create(C.byref(bad), C.byref(h)) == _lib.BHR_ERR_INVALID
     with pytest.raises(ValueError):
         _lib.check(_lib.BHR_ERR_INVALID)

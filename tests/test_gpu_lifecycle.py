@@ -16,7 +16,8 @@ def _renderer(n_r, n_phi, **kw):
 
 @pytest.mark.parametrize("n_r,n_phi", [(48, 96), (128, 336), (416, 2912)])
 def test_entity_layer_matches_host_rasteriser(hip_lib, n_r, n_phi):
-    from bhr_amd.lifecycle import make_factories, rasterize_entities
+    from bhr_amd.lifecycle import make_factories
+    from lifecycle_checker import rasterize_entities
     r = _renderer(n_r, n_phi)
     r.init_background_layer(n_r, n_phi, seed=42)
     fac = make_factories(n_r, n_phi, 2.0, 15.0, seed=42)
@@ -40,7 +41,8 @@ def test_entity_layer_matches_host_rasteriser(hip_lib, n_r, n_phi):
 
 def test_profile_pool_survives_turnover(hip_lib):
     """Many ticks: entities die and spawn, the pool is rebuilt; results stay equal to the host path."""
-    from bhr_amd.lifecycle import make_factories, rasterize_entities
+    from bhr_amd.lifecycle import make_factories
+    from lifecycle_checker import rasterize_entities
     n_r, n_phi = 48, 96
     r = _renderer(n_r, n_phi)
     r.init_background_layer(n_r, n_phi, seed=42)
@@ -58,18 +60,35 @@ def test_profile_pool_survives_turnover(hip_lib):
     r.close()
 
 
+def _use_host_lifecycle(r):
+    """Checker configuration: the entity layer and the statistics from the reference-identical NumPy forms
+    (tests/lifecycle_checker.py), uploaded through the C ABI -- what the device path is compared with."""
+    import bhr_amd._lib as L
+    from lifecycle_checker import compose_statistics, rasterize_entities
+
+    def accumulate(factories, now):
+        staging = rasterize_entities(factories, now, r._bg_n_r, r._bg_n_phi, r._bg_omega_all_np, r._bg_r_norm_all)
+        L.check(r._lib.bhr_set_entity_staging(r._ctx, L.fptr(staging)))
+
+    def stats():
+        r._set_stats(*compose_statistics(r.read_comp(), r._edge_np, r._param_enable_rt))
+
+    r.accumulate_entity_layer, r.recompute_interactive_stats = accumulate, stats
+
+
 @pytest.mark.parametrize("n_r,n_phi", [(48, 96), (416, 2912)])
 def test_statistics_match_numpy_exactly(hip_lib, n_r, n_phi):
-    from bhr_amd.lifecycle import compose_statistics, make_factories, rasterize_entities
+    from bhr_amd.lifecycle import make_factories
+    from lifecycle_checker import compose_statistics, rasterize_entities
     r = _renderer(n_r, n_phi)
     r.init_background_layer(n_r, n_phi, seed=42)
     fac = make_factories(n_r, n_phi, 2.0, 15.0, seed=42)
     r.generate_background(3.0)
-    r.device_lifecycle = False                           # upload the host staging: identical comp on both sides
+    _use_host_lifecycle(r)                               # upload the host staging: identical comp on both sides
     r.accumulate_entity_layer(fac, 0.0)
     comp = r.read_comp()
     want = compose_statistics(comp, r._edge_np, 1)
-    r.device_lifecycle = True
+    del r.accumulate_entity_layer, r.recompute_interactive_stats     # back to the product's device path
     r.recompute_interactive_stats()
     assert np.float32(want[0]) == r._stats_np[0] and np.float32(want[1]) == r._stats_np[1]
     np.testing.assert_array_equal(r._row_stats_np, want[2])
@@ -92,7 +111,8 @@ def test_device_and_host_lifecycle_render_the_same_frame(hip_lib):
     for dev in (True, False):
         r = HipRenderer(320, 180, scenes.analytic_skybox(64, 128), np.zeros((128, 336, 4), dtype=np.float32),
                         r_disk_inner=2.0, r_disk_outer=3.5, disk_tilt=15.0)
-        r.device_lifecycle = dev
+        if not dev:
+            _use_host_lifecycle(r)
         fac = init_lifecycle_system(r, 128, 336, seed=42)
         for k in range(1, 4):
             advance_lifecycle_frame(r, fac, t=0.1 * k, dt=0.1, recompute_stats=(k == 3))

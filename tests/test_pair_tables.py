@@ -19,24 +19,24 @@ class _Pool:
 def _filament_rows_scalar(e, now, n_r, omega_rows, r_norm_all):
     from bhr_amd.lifecycle import FILAMENT_BIRTH_FADE_DUR
     age = now - e.birth_time
-    s0 = max(e.blob_sigma_phi0, 1e-6)
-    sigma_phi = s0 + e.alpha_shear * age
-    amp_d, amp_t = e.blob_peak_density * s0 / sigma_phi, e.blob_peak_temp * s0 / sigma_phi
+    s0 = max(e.sigma_phi0, 1e-6)
+    sigma_phi = s0 + e.shear_rate * age
+    amp_d, amp_t = e.peak_density * s0 / sigma_phi, e.peak_temp * s0 / sigma_phi
     born = min(age / FILAMENT_BIRTH_FADE_DUR, 1.0) if FILAMENT_BIRTH_FADE_DUR > 0 else 1.0
-    cool = math.exp(-age / e.tau_cool) if e.tau_cool > 0 else 1.0
-    sigma_r = max(e.blob_sigma_r, 1e-6)
+    cool = math.exp(-age / e.cooling_time) if e.cooling_time > 0 else 1.0
+    sigma_r = max(e.sigma_r, 1e-6)
     inv_2s_r = 0.5 / (sigma_r * sigma_r)
     out = []
     for ri in e.row_indices:
         if 0 <= ri < n_r:
-            r_w = math.exp(-(r_norm_all[ri] - e.blob_base_r) ** 2 * inv_2s_r)
+            r_w = math.exp(-(r_norm_all[ri] - e.base_r) ** 2 * inv_2s_r)
             center = (np.float32(e.source_phi) - omega_rows[ri] * np.float32(age)) % np.float32(2 * np.pi)
             out.append((int(ri), float(center), 0.5 / (sigma_phi * sigma_phi), amp_d * born * cool * r_w, amp_t * born * cool * r_w))
     return out
 
 
 def test_pair_tables_match_scalar_expressions():
-    from bhr_amd.lifecycle import FILAMENT_DEATH_THRESHOLD, make_factories
+    from bhr_amd.lifecycle import FILAMENT_DEATH_THRESHOLD, envelope, filament_strength, make_factories
     from bhr_amd.lifecycle_device import filament_pairs, rolled_pairs
     n_r, n_phi = 96, 256
     fac = make_factories(n_r, n_phi, 2.0, 15.0, seed=42)
@@ -51,7 +51,7 @@ def test_pair_tables_match_scalar_expressions():
         rows, tab = filament_pairs(fac["filament"], now, n_r, omega_rows, r_norm_all)     # second call reuses the caches
         want = []
         for e in fac["filament"].alive_entities:
-            if e.density_factor(now - e.birth_time) >= FILAMENT_DEATH_THRESHOLD:
+            if filament_strength(e, now - e.birth_time) >= FILAMENT_DEATH_THRESHOLD:
                 want += _filament_rows_scalar(e, now, n_r, omega_rows, r_norm_all)
         assert len(want) == len(rows) > 0
         np.testing.assert_array_equal(rows, [w[0] for w in want])
@@ -62,7 +62,7 @@ def test_pair_tables_match_scalar_expressions():
         k = 0
         for key, plane in (("rt_spike", 2), ("hotspot", 4)):
             for e in fac[key].alive_entities:
-                alpha = e.fade_factor(now)
+                alpha = envelope(e, now)
                 if alpha <= 0:
                     continue
                 off, stride = pool.offset_of(e)
