@@ -188,7 +188,7 @@ int32_t bhr_fail(int32_t code, const char *fmt, ...) {
 
 int32_t bhr_enter(bhr_ctx *ctx) {
     BHR_HIP(hipSetDevice(ctx->cfg.device));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < BHR_MAX_FRAME_SLOTS; ++k) {
         bhr_frame_slot &f = ctx->slots[k];
         if (f.in_flight && f.stream != ctx->scene_stream) BHR_HIP(hipStreamWaitEvent(ctx->scene_stream, f.done, 0));
         f.in_flight = 0;
@@ -232,7 +232,8 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     ctx->scene_stream = ctx->stream;
     {
         const char *e = getenv("BHR_FRAME_SLOTS");       // 2 (default): frames alternate between two slots / streams
-        ctx->n_slots = (e && atoi(e) == 1) ? 1 : 2;
+        ctx->n_slots = e ? atoi(e) : 2;
+        if (ctx->n_slots < 1 || ctx->n_slots > BHR_MAX_FRAME_SLOTS) ctx->n_slots = 2;
     }
     if (hipEventCreateWithFlags(&ctx->scene_ev, hipEventDisableTiming) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipEventCreate failed"));
     for (auto &e : ctx->ev)
@@ -279,8 +280,7 @@ void bhr_destroy(bhr_ctx *ctx) {
     ctx->stream = ctx->scene_stream;
     free_scene(ctx);
     free_bg(ctx);
-    free_slot(ctx, 0);
-    free_slot(ctx, 1);
+    for (int k = 0; k < BHR_MAX_FRAME_SLOTS; ++k) free_slot(ctx, k);
     if (ctx->scene_ev) (void)hipEventDestroy(ctx->scene_ev);
     void *bufs[] = {ctx->d_skybox,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_noise_in,
@@ -483,9 +483,9 @@ int32_t render_on_slot(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags, int 
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     BHR_TRY(bhr_launch_march(ctx, cam, flags));  // records the ring slot's march events
     if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctx));
-    // the V kernel clears the counter cell of the frame after next: that frame runs on THIS stream again, whereas
-    // the next frame's march may already be counting on the other stream
-    ctx->v_zero_cell = ctx->d_steps_ring + (size_t)((ring + 2) % BHR_TIMING_RING) * BHR_STEP_CELL;
+    // the V kernel clears the counter cell BHR_MAX_FRAME_SLOTS frames ahead: no frame that may be in flight on another
+    // slot's stream is counting into it (the next frames' marches may already be running)
+    ctx->v_zero_cell = ctx->d_steps_ring + (size_t)((ring + BHR_MAX_FRAME_SLOTS) % BHR_TIMING_RING) * BHR_STEP_CELL;
     const int32_t rc_v = bhr_launch_bloom_v(ctx, with_bloom);
     ctx->v_zero_cell = nullptr;
     BHR_TRY(rc_v);
@@ -493,8 +493,10 @@ int32_t render_on_slot(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags, int 
         if (ctx->rows != ctx->cfg.height)
             return bhr_fail(BHR_ERR_INVALID, "bhr_render: the lens flare needs whole-frame sums; use bhr_group_render for row blocks");
         // the flare's scratch buffers are shared by the slots: wait for the other frame's passes
-        bhr_frame_slot &o = ctx->slots[k ^ 1];
-        if (o.in_flight && o.stream != f.stream) BHR_HIP(hipStreamWaitEvent(f.stream, o.done, 0));
+        for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q) {
+            bhr_frame_slot &o = ctx->slots[q];
+            if (q != k && o.in_flight && o.stream && o.stream != f.stream) BHR_HIP(hipStreamWaitEvent(f.stream, o.done, 0));
+        }
         BHR_TRY(bhr_launch_flare_glow(ctx, true));
         BHR_TRY(bhr_launch_flare_sums(ctx));
         BHR_TRY(bhr_launch_flare_apply(ctx, nullptr));
@@ -512,7 +514,7 @@ int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     // launches that use per-context scratch (work queue of the persistent schedule, row-cost profile) stay on one slot
     const bool exclusive = (flags & (BHR_PERSISTENT | BHR_ROW_COSTS)) != 0;
     if (exclusive) BHR_TRY(bhr_enter(ctx));
-    const int k = (ctx->n_slots == 2 && !exclusive) ? ctx->next_slot : 0;
+    const int k = (ctx->n_slots > 1 && !exclusive) ? ctx->next_slot : 0;
     BHR_TRY(alloc_slot(ctx, k));
     bhr_frame_slot &f = ctx->slots[k];
     if (!(flags & BHR_SKIP_BLOOM)) BHR_TRY(bhr_bloom_prepare(ctx));   // one-off tables, on the scene stream
@@ -528,7 +530,7 @@ int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     ctx->stream = ctx->scene_stream;
     f.in_flight = 1;
     BHR_TRY(rc);
-    if (ctx->n_slots == 2 && !exclusive) ctx->next_slot = k ^ 1;
+    if (ctx->n_slots > 1 && !exclusive) ctx->next_slot = (k + 1) % ctx->n_slots;
     ctx->last_slot = ring;
     ctx->ring_head += 1;
     ctx->last_flags = (int32_t)flags;
@@ -622,8 +624,8 @@ int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {
         ctx->counters.frame_ms = ev_ms(e[0], e[2]);
     }
     {
-        // the two cells after the head have been cleared for the frames to come: at most RING - 2 frames are on record
-        const int64_t n = ctx->ring_head < BHR_TIMING_RING - 2 ? ctx->ring_head : BHR_TIMING_RING - 2;
+        // the cells after the head have been cleared for the frames to come: at most RING - MAX_SLOTS frames are on record
+        const int64_t n = ctx->ring_head < BHR_TIMING_RING - BHR_MAX_FRAME_SLOTS ? ctx->ring_head : BHR_TIMING_RING - BHR_MAX_FRAME_SLOTS;
         float ms_m = 0.0f, ms_b = 0.0f;
         unsigned long long steps_sum = 0;
         if (n > 0) {

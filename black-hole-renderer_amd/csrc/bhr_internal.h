@@ -78,6 +78,7 @@ struct BhrMarchArgs {
 // stack, comp planes ...) is shared and read-only while frames are in flight (bhr_enter orders every other entry
 // point behind them).  Slot 1 is allocated at the second bhr_render; BHR_FRAME_SLOTS=1 keeps one slot on the
 // context's own stream (round 1 behaviour, isolated per-kernel timing).
+#define BHR_MAX_FRAME_SLOTS 4
 struct bhr_frame_slot {
     hipStream_t stream;
     float *d_bg, *d_disk, *d_hblur, *d_blur, *d_final;
@@ -93,7 +94,7 @@ struct bhr_ctx {
     int32_t rows;
     hipStream_t stream;                 // the stream launchers use: the scene stream, or a slot's during bhr_render
     hipStream_t scene_stream;           // scene updates, read-backs, group renders
-    bhr_frame_slot slots[2];
+    bhr_frame_slot slots[BHR_MAX_FRAME_SLOTS];
     int32_t n_slots, next_slot, active_slot;
     hipEvent_t scene_ev;                // scene stream -> slot stream ordering, recorded at every bhr_render
     hipEvent_t ev[8];

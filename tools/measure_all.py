@@ -20,7 +20,7 @@ for name, (W, H, step, tilt, aa) in cfgs.items():
     n_phi, n_r = compute_disk_texture_resolution(W, H, [6, 0, 0.5], 90, 2.0, 15.0)
     sky, tex = scenes.analytic_skybox(1024, 2048), scenes.noisy_disk(n_r, n_phi)
     for math in ("strict", "fast"):
-        r = HipRenderer(W, H, sky, tex, step_size=step, disk_tilt=tilt, anti_alias=aa, math=math)
+        r = HipRenderer(W, H, sky, tex, step_size=step, disk_tilt=tilt, anti_alias=aa, math=math, frame_slots=1)   # isolated launches
         m, b, steps, vg = timed(r, [6, 0, 0.5], 90, n=10 if W > 4000 else 20)
         res[f"{name}/{math}"] = dict(march_ms=round(m, 3), bloom_ms=round(b, 3), gsteps_per_s=round(steps / m / 1e6, 1), steps_per_ray=round(steps / W / H, 2), vgprs=vg)
         if name == "fhd" and math == "strict":
