@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--persistent", action="store_true", help="A/B: persistent waves + queue refill instead of the tile schedule")
     ap.add_argument("--no-other-math", action="store_true", help="skip the informational A/B leg (profiling)")
-    ap.add_argument("--frame-slots", type=int, default=None, choices=[1, 2, 3, 4],
+    ap.add_argument("--frame-slots", type=int, default=None, choices=[1, 2],
                     help="frames in flight per context (default 2: successive frames overlap on two streams)")
     ap.add_argument("--strong", action="store_true",
                     help="headline = ONE frame of --workload in --gpus row blocks (strong scaling; default for --workload 8k with N > 1)")

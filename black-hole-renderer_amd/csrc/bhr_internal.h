@@ -78,7 +78,8 @@ struct BhrMarchArgs {
 // stack, comp planes ...) is shared and read-only while frames are in flight (bhr_enter orders every other entry
 // point behind them).  Slot 1 is allocated at the second bhr_render; BHR_FRAME_SLOTS=1 keeps one slot on the
 // context's own stream (round 1 behaviour, isolated per-kernel timing).
-#define BHR_MAX_FRAME_SLOTS 4
+// two is the measured optimum (fhd strict: 1291 fps with one frame in flight, 1452 with two, 1389 / 1400 with three / four)
+#define BHR_MAX_FRAME_SLOTS 2
 struct bhr_frame_slot {
     hipStream_t stream;
     float *d_bg, *d_disk, *d_hblur, *d_blur, *d_final;

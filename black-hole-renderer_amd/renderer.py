@@ -79,8 +79,8 @@ class HipRenderer:
         # frame_slots: 2 (library default) = successive render_async calls alternate between two frame slots /
         # streams and overlap; 1 = one frame at a time on the context's stream (isolated kernel timing).  The
         # library reads BHR_FRAME_SLOTS when the context is created.
-        if frame_slots not in (None, 1, 2, 3, 4):
-            raise ValueError(f"frame_slots must be 1..4, got {frame_slots!r}")
+        if frame_slots not in (None, 1, 2):
+            raise ValueError(f"frame_slots must be 1 or 2, got {frame_slots!r}")
         saved = os.environ.get("BHR_FRAME_SLOTS")
         if frame_slots is not None:
             os.environ["BHR_FRAME_SLOTS"] = str(frame_slots)
@@ -93,7 +93,7 @@ class HipRenderer:
                 else:
                     os.environ["BHR_FRAME_SLOTS"] = saved
         self._ctx = handle
-        self.frame_slots = frame_slots if frame_slots is not None else (int(saved) if saved in ("1", "2", "3", "4") else 2)
+        self.frame_slots = frame_slots if frame_slots is not None else (1 if saved == "1" else 2)
 
         skybox = np.ascontiguousarray(skybox, dtype=np.float32)
         disk_tex = np.ascontiguousarray(disk_tex, dtype=np.float32)

@@ -114,7 +114,7 @@ typedef struct {
     int32_t march_vgprs;     /* registers per lane of the march kernel that ran (hipFuncGetAttributes) */
     int32_t march_lds_bytes;
     /* sums over the bhr_render calls since bhr_timing_reset (at most the last
-     * BHR_TIMING_RING - 4 calls), each launch bracketed by its own HIP events on its frame slot's stream */
+     * BHR_TIMING_RING - 2 calls), each launch bracketed by its own HIP events on its frame slot's stream */
     int32_t frames_timed;
     float march_ms_sum;
     float bloom_ms_sum;
