@@ -321,7 +321,7 @@ def main():
         }
         if n_other:
           out["other_math"] = {"math": other, "value": co["ray_steps"] * n_other / el_other / 1e6, "unit": "Mray-steps/s",
-                             "fps": n_other / el_other, "march_ms": co["march_ms_sum"] / max(co["frames_timed"], 1),
+                             "fps": n_other / el_other,
                              "note": "informational A/B in the same process; `value` above is the default (parity-certified) arithmetic"}
         if tile is not None:
             out["tile_scaling"] = tile
