@@ -20,7 +20,7 @@ LAYER_FINAL, LAYER_BG, LAYER_DISK, LAYER_BLUR = 0, 1, 2, 3
 # every symbol include/bhr.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
     "bhr_last_error", "bhr_abi_version", "bhr_device_count", "bhr_create", "bhr_destroy", "bhr_sync",
-    "bhr_set_skybox", "bhr_skybox_add_glow", "bhr_get_skybox", "bhr_set_disk_texture", "bhr_get_disk_texture", "bhr_get_disk_mip", "bhr_num_mip_levels",
+    "bhr_set_skybox", "bhr_skybox_add_glow", "bhr_skybox_build", "bhr_get_skybox", "bhr_set_disk_texture", "bhr_get_disk_texture", "bhr_get_disk_mip", "bhr_num_mip_levels",
     "bhr_bg_init", "bhr_generate_background", "bhr_set_entity_staging", "bhr_set_comp", "bhr_read_comp",
     "bhr_fill_comp_slice", "bhr_set_compose_stats", "bhr_compose_texture", "bhr_eval_noise", "bhr_render",
     "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_timing_reset", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_read_gathered", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities",
@@ -98,6 +98,8 @@ def load() -> C.CDLL:
     lib.bhr_render.argtypes = [P, C.POINTER(Camera), C.c_uint32]
     lib.bhr_read_layer.argtypes = [P, I32, F]
     lib.bhr_read_gathered.argtypes = [P, F]
+    PI32 = C.POINTER(C.c_int32)
+    lib.bhr_skybox_build.argtypes = [P, I32, I32, C.POINTER(C.c_uint8), I32, I32, PI32, PI32, I32, PI32, PI32, I32, I32, F, F, F, F, I32]
     lib.bhr_write_layer.argtypes = [P, I32, F]
     lib.bhr_bloom.argtypes = [P]
     lib.bhr_lens_flare.argtypes = [P]

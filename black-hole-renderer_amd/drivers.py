@@ -85,9 +85,15 @@ def make_renderer(width, height, cam_pos, fov, step_size=0.1, skybox_path=None, 
                   aa_strength=1.0, disk_rotation_speed=0.1, device_index=0, rows=None):
     """Renderer with a placeholder (or file) disk texture, as the reference's entry points build it
     (render.py:4044-4064, 4627-4644).  Returns (renderer, use_lifecycle, n_r, n_phi)."""
-    # procedural sky: the random part on the host, the closed-form Milky-Way glow on the device (skyglow.hip)
-    skybox, tex_h, tex_w = load_or_generate_skybox(skybox_path, tex_w, tex_h, n_stars, glow=False)
-    procedural_sky = load_or_generate_skybox.procedural
+    # procedural sky: the host draws its random tables, the device rasterises them (nebula resize, star blobs in
+    # NumPy's accumulation order, Milky-Way glow; skyglow.hip); an image file is loaded as it is
+    procedural_sky = not (skybox_path and os.path.isfile(skybox_path))
+    if procedural_sky:
+        print(f"Texture not found: {skybox_path}, generating procedural skybox..." if skybox_path
+              else "Generating procedural skybox...")
+        skybox = np.zeros((tex_h, tex_w, 3), dtype=np.float32)          # fixes the size; built on the device below
+    else:
+        skybox, tex_h, tex_w = load_or_generate_skybox(skybox_path, tex_w, tex_h, n_stars)
     disk_tex = load_disk_texture(disk_texture_path)
     use_lifecycle = disk_tex is None
     if use_lifecycle:
@@ -100,7 +106,7 @@ def make_renderer(width, height, cam_pos, fov, step_size=0.1, skybox_path=None, 
                            lens_flare=lens_flare, anti_alias=anti_alias, aa_strength=aa_strength,
                            disk_rotation_speed=disk_rotation_speed, device_index=device_index, rows=rows)
     if procedural_sky:
-        renderer.add_skybox_glow()
+        renderer.build_procedural_skybox(seed=42, n_stars=n_stars)
     return renderer, use_lifecycle, n_r, n_phi
 
 

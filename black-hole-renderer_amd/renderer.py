@@ -137,6 +137,24 @@ class HipRenderer:
         constructor must be generate_skybox(..., glow=False)."""
         _lib.check(self._lib.bhr_skybox_add_glow(self._ctx))
 
+    def build_procedural_skybox(self, seed: int = 42, n_stars: int = 6000) -> None:
+        """generate_skybox(tex_w, tex_h, seed, n_stars) (render.py:153-341) into this renderer's skybox, on the
+        device: the host draws the random tables (skybox.sky_tables), bhr_skybox_build rasterises them bit-identically
+        to NumPy / Pillow, bhr_skybox_add_glow adds the Milky-Way glow and clips.  The skybox given to the constructor
+        only fixes the size."""
+        from .skybox import STAR_PATCH_R, pillow_bilinear_coeffs, sky_tables
+        t = sky_tables(self.tex_w, self.tex_h, seed, n_stars)
+        ch, cw = t["coarse_u8"].shape[:2]
+        kh, bh = pillow_bilinear_coeffs(cw, self.tex_w)
+        kv, bv = pillow_bilinear_coeffs(ch, self.tex_h)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32))   # noqa: E731
+        coarse = np.ascontiguousarray(t["coarse_u8"])
+        _lib.check(self._lib.bhr_skybox_build(
+            self._ctx, self.tex_h, self.tex_w, coarse.ctypes.data_as(C.POINTER(C.c_uint8)), ch, cw, i32(kh), i32(bh), kh.shape[1],
+            i32(kv), i32(bv), kv.shape[1], len(t["cx"]), _lib.fptr(t["cx"]), _lib.fptr(t["cy"]), _lib.fptr(t["colors"]),
+            _lib.fptr(t["vals"]), STAR_PATCH_R))
+        self.add_skybox_glow()
+
     def read_skybox(self) -> np.ndarray:
         out = np.empty((self.tex_h, self.tex_w, 3), dtype=np.float32)
         _lib.check(self._lib.bhr_get_skybox(self._ctx, _lib.fptr(out)))

@@ -91,19 +91,16 @@ def _star_masses_and_magnitudes(rng, n_stars):
     return mass[pick], app_mag[pick]
 
 
-def generate_skybox(tex_w: int = 2048, tex_h: int = 1024, seed: int = 42, n_stars: int = 6000, glow: bool = True) -> np.ndarray:
-    """(tex_h, tex_w, 3) float32 in [0, 1], seamless in u.  ``glow=False`` stops before the Milky-Way glow and
-    the final clip: the order-sensitive random part (nebula + star splats), to which the device adds the glow
-    (HipRenderer.add_skybox_glow, csrc/skyglow.hip)."""
-    from PIL import Image
+STAR_PATCH_R = 4            # 9 x 9 blob
 
+
+def sky_tables(tex_w: int = 2048, tex_h: int = 1024, seed: int = 42, n_stars: int = 6000) -> dict:
+    """Everything of generate_skybox that comes out of the random stream (render.py:153-262), in its draw order:
+    the nebula noise quantised to u8 at 1/16 resolution, and per star its texel centre, colour and the values of its
+    Gaussian blob.  The per-texel work on these tables is `rasterize_sky` on the host or bhr_skybox_build on the device."""
     rng = np.random.default_rng(seed)
-    sky = np.full((tex_h, tex_w, 3), 0.003, dtype=np.float32)
-
-    # nebula: 1/16-resolution noise, bilinearly upsampled through 8-bit
     coarse = rng.random((tex_h // 16, tex_w // 16, 3)).astype(np.float32) * 0.06
-    coarse_u8 = Image.fromarray((coarse * 255).astype(np.uint8))
-    sky += np.array(coarse_u8.resize((tex_w, tex_h), Image.Resampling.BILINEAR)) / 255.0 * 0.04
+    coarse_u8 = (coarse * 255).astype(np.uint8)
 
     phi_s, theta_s = _star_positions(rng, n_stars)
     cx = (phi_s / (2 * np.pi) * tex_w).astype(np.float32)
@@ -119,20 +116,61 @@ def generate_skybox(tex_w: int = 2048, tex_h: int = 1024, seed: int = 42, n_star
     colors = blackbody_rgb(temp_K)
     colors = STAR_COLOR_SATURATION * colors + (1 - STAR_COLOR_SATURATION) * np.ones_like(colors)
 
-    # splat 9x9 Gaussian blobs, wrapping in u, clipping in v
-    R = 4
-    offs = np.arange(-R, R + 1, dtype=np.float32)
+    offs = np.arange(-STAR_PATCH_R, STAR_PATCH_R + 1, dtype=np.float32)
     dy_grid, dx_grid = np.meshgrid(offs, offs, indexing="ij")
     dy, dx = dy_grid.ravel(), dx_grid.ravel()
-    n_patch = len(dy)
-    px = (cx[:, None] + dx[None, :]).astype(int) % tex_w
-    py = (cy[:, None] + dy[None, :]).astype(int)
     d2 = dx[None, :] ** 2 + dy[None, :] ** 2
     vals = brightness[:, None] * np.exp(-d2 / (2 * sigma[:, None] ** 2))
+    return dict(tex_w=tex_w, tex_h=tex_h, coarse_u8=coarse_u8, cx=cx, cy=cy, colors=np.ascontiguousarray(colors, dtype=np.float32),
+                vals=np.ascontiguousarray(vals, dtype=np.float32), dx=dx, dy=dy)
+
+
+def pillow_bilinear_coeffs(in_size: int, out_size: int):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter (src/libImaging/Resample.c):
+    -> (k (out_size, ksize) int32 weights with 22 fractional bits, bounds (out_size, 2) int32 = first source index,
+    tap count).  tests/test_golden_host.py checks the two-pass resize built from these against Image.resize."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), dtype=np.float64)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        n = min(int(center + support + 0.5), in_size) - xmin
+        w = 1.0 - np.abs((np.arange(n) + xmin - center + 0.5) * ss)
+        w = np.where(w > 0.0, w, 0.0)
+        tot = w.sum()
+        kk[xx, :n] = w / tot if tot != 0.0 else w
+        bounds[xx] = (xmin, n)
+    fixed = np.where(kk < 0, -0.5 + kk * (1 << 22), 0.5 + kk * (1 << 22)).astype(np.int64)     # C (int): toward zero
+    return np.ascontiguousarray(fixed.astype(np.int32)), bounds
+
+
+def rasterize_sky(t: dict) -> np.ndarray:
+    """Host form of the per-texel work (the reference's own NumPy / Pillow calls): nebula upsampled through 8-bit
+    with Image.resize, star blobs through np.add.at.  (tex_h, tex_w, 3) float32, before the glow."""
+    from PIL import Image
+    tex_w, tex_h = t["tex_w"], t["tex_h"]
+    sky = np.full((tex_h, tex_w, 3), 0.003, dtype=np.float32)
+    sky += np.array(Image.fromarray(t["coarse_u8"]).resize((tex_w, tex_h), Image.Resampling.BILINEAR)) / 255.0 * 0.04
+    cx, cy, dx, dy, vals, colors = t["cx"], t["cy"], t["dx"], t["dy"], t["vals"], t["colors"]
+    n_patch = len(dy)
+    px = (cx[:, None] + dx[None, :]).astype(int) % tex_w          # wrap in u
+    py = (cy[:, None] + dy[None, :]).astype(int)                  # clip in v
     ok = (py >= 0) & (py < tex_h)
     contrib = np.repeat(colors, n_patch, axis=0)[ok.ravel()] * vals[ok][:, None]
     np.add.at(sky, (py[ok], px[ok]), contrib)
+    return sky
 
+
+def generate_skybox(tex_w: int = 2048, tex_h: int = 1024, seed: int = 42, n_stars: int = 6000, glow: bool = True) -> np.ndarray:
+    """(tex_h, tex_w, 3) float32 in [0, 1], seamless in u -- entirely on the host (the reference's result, pinned by
+    tests/golden/skybox.npz; the product builds the same texture on the device: HipRenderer.build_procedural_skybox).
+    ``glow=False`` stops before the Milky-Way glow and the final clip."""
+    sky = rasterize_sky(sky_tables(tex_w, tex_h, seed, n_stars))
     if not glow:
         return sky
 

@@ -11,18 +11,16 @@ def make_scene(wl: dict, device_index: int = 0, n_stars: int = 6000, math=None, 
     """Renderer for workload ``wl`` (see bench.WORKLOADS) with the reference's default scene:
     procedural skybox (generate_skybox(2048, 1024, seed 42)) and the lifecycle disk texture at
     t = 0 (render_image, render.py:4044-4069).  Returns (renderer, skybox, disk_tex, note)."""
-    from .skybox import generate_skybox
     from .drivers import init_lifecycle_system, advance_lifecycle_frame
 
     W, H = wl["width"], wl["height"]
     r_in, r_out = 2.0, 15.0
     n_phi, n_r = compute_disk_texture_resolution(W, H, wl["cam_pos"], wl["fov"], r_in, r_out)
-    sky = generate_skybox(2048, 1024, seed=42, n_stars=n_stars, glow=False)     # + the glow on the device, below
     placeholder = np.zeros((n_r, n_phi, 4), dtype=np.float32)
-    r = HipRenderer(W, H, sky, placeholder, step_size=wl["step_size"], r_max=10.0, r_disk_inner=r_in,
-                    r_disk_outer=r_out, disk_tilt=wl["disk_tilt"], anti_alias=wl["anti_alias"],
+    r = HipRenderer(W, H, np.zeros((1024, 2048, 3), dtype=np.float32), placeholder, step_size=wl["step_size"], r_max=10.0,
+                    r_disk_inner=r_in, r_disk_outer=r_out, disk_tilt=wl["disk_tilt"], anti_alias=wl["anti_alias"],
                     device_index=device_index, frame_slots=frame_slots, **({} if math is None else {"math": math}))
-    r.add_skybox_glow()
+    r.build_procedural_skybox(seed=42, n_stars=n_stars)              # random tables on the host, texels on the device
     sky = r.read_skybox()
     factories = init_lifecycle_system(r, n_r, n_phi, seed=42)
     advance_lifecycle_frame(r, factories, t=0.0, dt=0.0, recompute_stats=True)
@@ -36,7 +34,6 @@ def make_tiles(wl: dict, devices, n_stars: int = 6000, math=None, balance: bool 
     """Row-block renderers for ONE frame of workload ``wl`` (BASELINE.json configs[3]): block k on HIP device
     ``devices[k]``, every device with its own copy of the deterministic scene, rows cut by the cost profile of a
     probe frame (multigpu.balanced_row_blocks).  Returns (tiles, blocks, note); render with multigpu.group_render."""
-    from .skybox import generate_skybox
     from .drivers import init_lifecycle_system, advance_lifecycle_frame
     from . import multigpu
 
@@ -49,13 +46,13 @@ def make_tiles(wl: dict, devices, n_stars: int = 6000, math=None, balance: bool 
     if balance and n > 1 and H >= 64 * n:
         per_row, band_rows = multigpu.probe_row_costs(W, H, wl["cam_pos"], wl["fov"], device_index=devices[0], **kw)
         blocks = multigpu.balanced_row_blocks(H, n, per_row, band_rows, fixed_cost_per_row=0.1 * float(per_row.mean()))
-    sky = generate_skybox(2048, 1024, seed=42, n_stars=n_stars, glow=False)
+    sky = np.zeros((1024, 2048, 3), dtype=np.float32)
     placeholder = np.zeros((n_r, n_phi, 4), dtype=np.float32)
     tiles = []
     for dev, rows in zip(devices, blocks):
         r = HipRenderer(W, H, sky, placeholder, anti_alias=wl["anti_alias"], device_index=dev, rows=rows, frame_slots=1,
                         **kw, **({} if math is None else {"math": math}))
-        r.add_skybox_glow()
+        r.build_procedural_skybox(seed=42, n_stars=n_stars)
         factories = init_lifecycle_system(r, n_r, n_phi, seed=42)
         advance_lifecycle_frame(r, factories, t=0.0, dt=0.0, recompute_stats=True)
         tiles.append(r)

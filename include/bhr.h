@@ -139,6 +139,17 @@ BHR_API int32_t bhr_set_skybox(bhr_ctx *ctx, const float *rgb, int32_t tex_h, in
  * its clip(0, 1): upload the sky WITHOUT the glow (nebula + stars, the order-sensitive host part), call this once.
  * bhr_get_skybox reads the texture back ((tex_h, tex_w, 3) f32).  Asynchronous / synchronous. */
 BHR_API int32_t bhr_skybox_add_glow(bhr_ctx *ctx);
+/* generate_skybox's nebula and star splats (render.py:167-295) on the device, into the (tex_h, tex_w, 3) skybox a
+ * previous bhr_set_skybox allocated.  The host supplies what comes out of NumPy's random stream: the 1/16-resolution
+ * nebula noise as u8 (coarse_h, coarse_w, 3) with Pillow's fixed-point BILINEAR coefficients for both passes (kh:
+ * (tex_w, ksize_h) 22-bit weights, bounds_h: (tex_w, 2) first source column and tap count; kv / bounds_v likewise for
+ * rows), and per star its centre (cx, cy: f32 texel coordinates), colour (n, 3) and blob values (n, (2 patch_r + 1)^2).
+ * The device reproduces Pillow's resize, `sky = 0.003 + resized / 255.0 * 0.04` and np.add.at's accumulation order bit
+ * for bit.  Follow with bhr_skybox_add_glow.  Synchronises. */
+BHR_API int32_t bhr_skybox_build(bhr_ctx *ctx, int32_t tex_h, int32_t tex_w, const uint8_t *coarse_rgb, int32_t coarse_h,
+                                 int32_t coarse_w, const int32_t *kh, const int32_t *bounds_h, int32_t ksize_h,
+                                 const int32_t *kv, const int32_t *bounds_v, int32_t ksize_v, int32_t n_stars,
+                                 const float *cx, const float *cy, const float *colors, const float *vals, int32_t patch_r);
 BHR_API int32_t bhr_get_skybox(bhr_ctx *ctx, float *out);
 /* disk_texture_field.from_numpy + generate_disk_mipmaps(levels=4) + padded
  * upload (render.py:2235-2251, update_disk_texture 2292-2312).  (n_r, n_phi, 4)

@@ -149,3 +149,41 @@ def test_numpy_lerp_replicates_percentile_and_quantile():
     lo, hi, g = linear_rank(2912, np.float32(0.7))
     got = np.array([numpy_lerp(r[lo], r[hi], g) for r in s], dtype=np.float32)
     np.testing.assert_array_equal(got, np.quantile(m, 0.7, axis=1).astype(np.float32))
+
+
+def test_pillow_bilinear_coefficients_reproduce_image_resize():
+    """skybox.pillow_bilinear_coeffs feeds the device's nebula resize (csrc/skyglow.hip): the two fixed-point passes
+    built from it must equal Pillow's Image.resize(..., BILINEAR) on u8 RGB, bit for bit."""
+    from PIL import Image
+    from bhr_amd.skybox import pillow_bilinear_coeffs
+
+    def resize(img, out_w, out_h):
+        h, w, c = img.shape
+        (kh, bh), (kv, bv) = pillow_bilinear_coeffs(w, out_w), pillow_bilinear_coeffs(h, out_h)
+        tmp = np.zeros((h, out_w, c), dtype=np.uint8)
+        for xx in range(out_w):
+            acc = np.full((h, c), 1 << 21, dtype=np.int64)
+            for x in range(bh[xx, 1]):
+                acc += img[:, bh[xx, 0] + x].astype(np.int64) * int(kh[xx, x])
+            tmp[:, xx] = np.clip(acc >> 22, 0, 255)
+        out = np.zeros((out_h, out_w, c), dtype=np.uint8)
+        for yy in range(out_h):
+            acc = np.full((out_w, c), 1 << 21, dtype=np.int64)
+            for y in range(bv[yy, 1]):
+                acc += tmp[bv[yy, 0] + y].astype(np.int64) * int(kv[yy, y])
+            out[yy] = np.clip(acc >> 22, 0, 255)
+        return out
+
+    rng = np.random.default_rng(3)
+    for (h, w, H, W) in ((64, 128, 1024, 2048), (2, 4, 32, 64), (8, 16, 128, 256), (5, 7, 80, 112)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = np.array(Image.fromarray(img).resize((W, H), Image.Resampling.BILINEAR))
+        np.testing.assert_array_equal(resize(img, W, H), want)
+
+
+def test_sky_tables_plus_rasterize_is_generate_skybox():
+    from bhr_amd.skybox import generate_skybox, rasterize_sky, sky_tables
+    d = g("skybox.npz")
+    np.testing.assert_array_equal(rasterize_sky(sky_tables(64, 32, seed=42, n_stars=10)),
+                                  generate_skybox(64, 32, seed=42, n_stars=10, glow=False))
+    np.testing.assert_array_equal(generate_skybox(64, 32, seed=42, n_stars=10), d["small"])      # the reference's texture

@@ -193,3 +193,32 @@ def test_skybox_glow_on_the_device(hip_lib, tex_w, tex_h, n_stars):
     assert np.abs(got - want).max() <= 6e-8
     assert (got != want).mean() < 1e-3                                        # and almost everywhere the same bits
     r.close()
+
+
+@pytest.mark.parametrize("tex_h,tex_w,n_stars", [(1024, 2048, 6000), (64, 128, 40), (128, 512, 300)])
+def test_procedural_skybox_on_the_device(hip_lib, tex_h, tex_w, n_stars):
+    """bhr_skybox_build: nebula (Pillow's bilinear resize through u8) + star blobs (np.add.at's order) on the device
+    are BIT-IDENTICAL to the host's NumPy / Pillow result; with the glow the texture is the reference's
+    generate_skybox to the last bit of the f64 transcendentals (SHA-256-pinned host generator as the checker)."""
+    from bhr_amd import HipRenderer
+    from bhr_amd.skybox import generate_skybox
+    r = HipRenderer(32, 18, np.zeros((tex_h, tex_w, 3), np.float32), np.zeros((16, 32, 4), np.float32))
+    r.build_procedural_skybox(seed=42, n_stars=n_stars)
+    got = r.read_skybox()
+    want = generate_skybox(tex_w, tex_h, seed=42, n_stars=n_stars)
+    assert np.abs(got - want).max() <= 6e-8 and (got != want).mean() < 2e-3
+    # before the glow: exact
+    from bhr_amd import _lib
+    from bhr_amd.skybox import STAR_PATCH_R, pillow_bilinear_coeffs, sky_tables
+    import ctypes as C
+    t = sky_tables(tex_w, tex_h, 42, n_stars)
+    kh, bh = pillow_bilinear_coeffs(t["coarse_u8"].shape[1], tex_w)
+    kv, bv = pillow_bilinear_coeffs(t["coarse_u8"].shape[0], tex_h)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int32))   # noqa: E731
+    coarse = np.ascontiguousarray(t["coarse_u8"])
+    _lib.check(r._lib.bhr_skybox_build(r._ctx, tex_h, tex_w, coarse.ctypes.data_as(C.POINTER(C.c_uint8)), coarse.shape[0],
+                                       coarse.shape[1], i32(kh), i32(bh), kh.shape[1], i32(kv), i32(bv), kv.shape[1],
+                                       len(t["cx"]), _lib.fptr(t["cx"]), _lib.fptr(t["cy"]), _lib.fptr(t["colors"]),
+                                       _lib.fptr(t["vals"]), STAR_PATCH_R))
+    np.testing.assert_array_equal(r.read_skybox(), generate_skybox(tex_w, tex_h, seed=42, n_stars=n_stars, glow=False))
+    r.close()
