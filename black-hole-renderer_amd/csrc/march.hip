@@ -921,8 +921,14 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // The texture kernels are held to 128 VGPRs (4 waves per SIMD): the strict arithmetic is a chain of dependent
 // exact-rounding sequences and needs the waves to cover its latency (measured at 4k with AA: 141 VGPRs / 3 waves
 // 7.6 ms, 128 / 4 waves 6.7 ms).  The binary64 Disk V2 instantiations take what they need.
+// BHR_ILP_WAVES (A/B knob, ILP-scheduled strict object only): pin the waves per SIMD the register allocator aims for
+#if BHR_MARCH_STRICT && BHR_MARCH_ILP && defined(BHR_ILP_WAVES)
+#define BHR_TILE_OCC __attribute__((amdgpu_waves_per_eu(BHR_ILP_WAVES, BHR_ILP_WAVES)))
+#else
+#define BHR_TILE_OCC
+#endif
 template <bool DIFF, int SRC = 0>
-__global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
+__global__ __launch_bounds__(256) BHR_TILE_OCC void march_tile_kernel(BhrMarchArgs a) {
     const int lane = threadIdx.x & 63;
     // one 8x8 tile per wave, tiles in row-major order; blockDim.x / 64 waves per block
     const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
