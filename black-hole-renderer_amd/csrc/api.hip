@@ -260,7 +260,7 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     int32_t v = 0, l = 0;
     if (cfg->math_mode != BHR_MATH_FAST && cfg->math_mode != BHR_MATH_STRICT)
         return bail(bhr_fail(BHR_ERR_INVALID, "bhr_create: math_mode %d", cfg->math_mode));
-    if ((cfg->math_mode == BHR_MATH_STRICT ? (cfg->anti_alias != 0 ? bhr_march_resources_strict(&v, &l, 1)
+    if ((cfg->math_mode == BHR_MATH_STRICT ? (cfg->anti_alias != 0 ? bhr_march_resources_strict_ilp(&v, &l, 1)
                                                                    : bhr_march_resources_strict_ilp(&v, &l, 0))
                                            : bhr_march_resources(&v, &l, cfg->anti_alias != 0)) == BHR_OK) {
         ctx->counters.march_vgprs = v;

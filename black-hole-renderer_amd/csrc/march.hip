@@ -48,9 +48,10 @@
 #define BHR_MARCH_ILP 0
 #endif
 #if BHR_MARCH_STRICT && BHR_MARCH_ILP
-// third compilation: the strict source scheduled with -mllvm -amdgpu-sched-strategy=max-ilp.  Only its plain
-// texture kernel (no differentials) is launched: that one gains 4 % from the ILP-first schedule (0.752 -> 0.720 ms,
-// 95 -> 105 VGPRs), the AA kernel loses 1.6 % and the fast build 3 %, so they keep the default scheduler.
+// third compilation: the strict source scheduled with -mllvm -amdgpu-sched-strategy=max-ilp.  Its two texture kernels
+// are launched (march_tile_plain_ilp, march_tile_aa_ilp, each with its own occupancy target): the plain one gains 4 %
+// from the ILP-first schedule, the AA one 1-2 % once held to 4 waves per SIMD (unconstrained it took 134 VGPRs and
+// lost 1.6 %); the fast build loses 3 % and keeps the default scheduler, as do the Disk V2 and persistent kernels.
 #define BHR_LAUNCH_MARCH bhr_launch_march_strict_ilp
 #define BHR_MARCH_RESOURCES bhr_march_resources_strict_ilp
 #elif BHR_MARCH_STRICT
@@ -921,14 +922,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // The texture kernels are held to 128 VGPRs (4 waves per SIMD): the strict arithmetic is a chain of dependent
 // exact-rounding sequences and needs the waves to cover its latency (measured at 4k with AA: 141 VGPRs / 3 waves
 // 7.6 ms, 128 / 4 waves 6.7 ms).  The binary64 Disk V2 instantiations take what they need.
-// BHR_ILP_WAVES (A/B knob, ILP-scheduled strict object only): pin the waves per SIMD the register allocator aims for
-#if BHR_MARCH_STRICT && BHR_MARCH_ILP && defined(BHR_ILP_WAVES)
-#define BHR_TILE_OCC __attribute__((amdgpu_waves_per_eu(BHR_ILP_WAVES, BHR_ILP_WAVES)))
-#else
-#define BHR_TILE_OCC
-#endif
 template <bool DIFF, int SRC = 0>
-__global__ __launch_bounds__(256) BHR_TILE_OCC void march_tile_kernel(BhrMarchArgs a) {
+__device__ __forceinline__ void march_tile_body(BhrMarchArgs a) {
     const int lane = threadIdx.x & 63;
     // one 8x8 tile per wave, tiles in row-major order; blockDim.x / 64 waves per block
     const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -966,6 +961,17 @@ __global__ __launch_bounds__(256) BHR_TILE_OCC void march_tile_kernel(BhrMarchAr
         if (a.row_steps && tile < a.n_tiles) atomicAdd(a.row_steps + ty, tot + (unsigned long long)flushes * (64u * BHR_FLUSH_COST));
     }
 }
+
+template <bool DIFF, int SRC = 0>
+__global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) { march_tile_body<DIFF, SRC>(a); }
+
+#if BHR_MARCH_STRICT && BHR_MARCH_ILP
+// The ILP-scheduled object launches two kernels, each with the occupancy its register allocation should aim for
+// (A/B on fhd / 4k, isolated launches): plain texture march at 5 waves per SIMD (96 VGPRs, no spills; 0.697 -> 0.692 ms,
+// 6 waves: 0.695), AA march at 4 (128 VGPRs; 6.50 -> 6.39 ms at 4k against the default scheduler).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void march_tile_plain_ilp(BhrMarchArgs a) { march_tile_body<false, 0>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void march_tile_aa_ilp(BhrMarchArgs a) { march_tile_body<true, 0>(a); }
+#endif
 
 // ---------------------------------------------------------------------------
 // persistent schedule: waves pull pixels from a queue (8x8-tile-major order, so refilled lanes
@@ -1109,7 +1115,11 @@ static int32_t ensure_tile_order(bhr_ctx *ctx, int tiles_x, int n_tiles) {
 
 int32_t BHR_MARCH_RESOURCES(int32_t *vgprs, int32_t *lds, int32_t diff) {
     hipFuncAttributes at;
+#if BHR_MARCH_STRICT && BHR_MARCH_ILP
+    const void *f = diff ? (const void *)march_tile_aa_ilp : (const void *)march_tile_plain_ilp;
+#else
     const void *f = diff ? (const void *)march_tile_kernel<true, 0> : (const void *)march_tile_kernel<false, 0>;
+#endif
     BHR_HIP(hipFuncGetAttributes(&at, f));
     *vgprs = at.numRegs;
     *lds = (int32_t)at.sharedSizeBytes;
@@ -1127,9 +1137,8 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     }
 #endif
 #if BHR_MARCH_STRICT && !BHR_MARCH_ILP
-    // the plain texture kernel lives in the ILP-scheduled object (see the top of this file)
-    if (!(c.anti_alias != 0 && !(flags & BHR_SKIP_DIFFERENTIALS)) && ctx->disk_source == BHR_DISK_TEXTURE &&
-        !(flags & BHR_PERSISTENT))
+    // the texture kernels (plain and AA) live in the ILP-scheduled object (see the top of this file)
+    if (ctx->disk_source == BHR_DISK_TEXTURE && !(flags & BHR_PERSISTENT))
         return bhr_launch_march_strict_ilp(ctx, cam, flags);
 #endif
     if (!ctx->d_skybox) return bhr_fail(BHR_ERR_STATE, "bhr_render: no skybox set (bhr_set_skybox)");
@@ -1235,11 +1244,19 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
                 hipLaunchKernelGGL((march_tile_kernel<true, 1>), grid, block, 0, ctx->stream, a);
             else
                 hipLaunchKernelGGL((march_tile_kernel<false, 1>), grid, block, 0, ctx->stream, a);
+#if BHR_MARCH_STRICT && BHR_MARCH_ILP
+        } else if (want_diff) {
+            hipLaunchKernelGGL(march_tile_aa_ilp, grid, block, 0, ctx->stream, a);
+        } else {
+            hipLaunchKernelGGL(march_tile_plain_ilp, grid, block, 0, ctx->stream, a);
+        }
+#else
         } else if (want_diff) {
             hipLaunchKernelGGL((march_tile_kernel<true, 0>), grid, block, 0, ctx->stream, a);
         } else {
             hipLaunchKernelGGL((march_tile_kernel<false, 0>), grid, block, 0, ctx->stream, a);
         }
+#endif
     } else {
         // enough resident waves to fill the chip; every wave drains the queue and exits
         int blocks = (a.n_tiles + 3) / 4;

@@ -33,6 +33,7 @@ PARAMS = dict(width=320, height=180, cam_pos=[6, 0, 0.5], fov=60, step_size=0.1,
 
 
 def main():
+    out_dir = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE
     keep = {}
     orig_init = ref.TaichiRenderer.__init__
 
@@ -51,7 +52,7 @@ def main():
     with open(os.path.join(REF, "tests", "e2e_baseline.txt")) as f:
         baseline = f.read().strip()
     print("md5 of this evaluation:", md5, " reference baseline:", baseline)
-    np.savez_compressed(os.path.join(HERE, "e2e_ref.npz"), final=img, md5=md5, baseline_md5=baseline,
+    np.savez_compressed(os.path.join(out_dir, "e2e_ref.npz"), final=img, md5=md5, baseline_md5=baseline,
                         sky_sha256=keep["sky_sha256"], disk_tex=r.disk_texture_field.to_numpy(),
                         stats=r._param_stats_field.to_numpy(), row_stats=r._param_row_stats_field.to_numpy())
 
