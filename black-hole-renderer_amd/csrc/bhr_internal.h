@@ -69,6 +69,7 @@ struct BhrMarchArgs {
     int32_t vol_substeps;
     const int32_t *tile_order;   // launch slot -> tile (nullptr: row-major)
     unsigned long long *row_steps;   // BHR_ROW_COSTS: ray-steps per 8-row band (nullptr: not collected)
+    unsigned long long *wave_stamps; // diagnostic (env BHR_WAVE_STAMPS): per wave s_memrealtime at start / end, steps, XCC|CU id
     int32_t n_tiles;         // 8x8 pixel tiles in the row block
     int32_t tiles_x;
 };

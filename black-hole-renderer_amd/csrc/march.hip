@@ -32,6 +32,7 @@
 //                   the reference's order with IEEE sqrt and divide, so that positions, step
 //                   counts and hit points are bit-identical to a strict f32 evaluation of
 //                   render.py:2854-3006 (selected with bhr_config.math_mode = 1).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -923,10 +924,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // exact-rounding sequences and needs the waves to cover its latency (measured at 4k with AA: 141 VGPRs / 3 waves
 // 7.6 ms, 128 / 4 waves 6.7 ms).  The binary64 Disk V2 instantiations take what they need.
 template <bool DIFF, int SRC = 0>
-__device__ __forceinline__ void march_tile_body(BhrMarchArgs a) {
+__device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int slot) {
     const int lane = threadIdx.x & 63;
-    // one 8x8 tile per wave, tiles in row-major order; blockDim.x / 64 waves per block
-    const int slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // one 8x8 tile per wave; `slot` is its position in the launch order
     // tiles are handed out longest first (tile_order: by distance from the image of the hole, where rays take the
     // most steps), so that the launch does not end on a few late, long waves
     const int tile = (a.tile_order && slot < a.n_tiles) ? a.tile_order[slot] : slot;
@@ -935,6 +935,7 @@ __device__ __forceinline__ void march_tile_body(BhrMarchArgs a) {
     const int j = ty * 8 + (lane >> 3);
     const bool valid = tile < a.n_tiles && i < a.width && j < a.rows;
 
+    const unsigned long long t_start = a.wave_stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     Ray<DIFF, SRC> ray;
     ray.init(a, valid ? i : 0, valid ? j : 0);
     if (!valid) ray.done = 4;
@@ -959,18 +960,46 @@ __device__ __forceinline__ void march_tile_body(BhrMarchArgs a) {
         // BHR_ROW_COSTS: cost profile over tile rows = ray-steps + the wave's shading passes, each priced as
         // BHR_FLUSH_COST wave-steps (a pass is ~1000 instructions, a strict step ~220)
         if (a.row_steps && tile < a.n_tiles) atomicAdd(a.row_steps + ty, tot + (unsigned long long)flushes * (64u * BHR_FLUSH_COST));
+        if (a.wave_stamps && slot < a.n_tiles) {          // diagnostic: when this wave lived (100 MHz ticks) and what it did
+            unsigned long long *w = a.wave_stamps + (size_t)slot * 4;
+            w[0] = t_start;
+            w[1] = __builtin_amdgcn_s_memrealtime();
+            w[2] = tot | ((unsigned long long)flushes << 40);
+            w[3] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        }
     }
 }
 
 template <bool DIFF, int SRC = 0>
-__global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) { march_tile_body<DIFF, SRC>(a); }
+__global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
+    march_tile_body<DIFF, SRC>(a, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+}
 
 #if BHR_MARCH_STRICT && BHR_MARCH_ILP
 // The ILP-scheduled object launches two kernels, each with the occupancy its register allocation should aim for
 // (A/B on fhd / 4k, isolated launches): plain texture march at 5 waves per SIMD (96 VGPRs, no spills; 0.697 -> 0.692 ms,
 // 6 waves: 0.695), AA march at 4 (128 VGPRs; 6.50 -> 6.39 ms at 4k against the default scheduler).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void march_tile_plain_ilp(BhrMarchArgs a) { march_tile_body<false, 0>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void march_tile_aa_ilp(BhrMarchArgs a) { march_tile_body<true, 0>(a); }
+// BHR_TPW tiles per wave, one after the other (a fixed, uniform trip count; wave w takes tiles w, w + W, w + 2W ... of
+// the launch order, W = waves in the launch).  Measured for the default: the per-wave timeline (tools/wave_timeline.py)
+// shows 88-92 % slot occupancy in the body of an fhd launch and a ~90 us ragged end; blocks of 64 threads (4x the
+// workgroups) take 0.89 ms instead of 0.69, so the workgroup dispatcher matters -- but 2 / 3 / 4 tiles per wave do not
+// buy it back (0.696 / 0.717 / 0.726 ms against 0.679 at one; 1501 fps with two frames in flight at 2, 1498 at 1).
+// One tile per wave stays; a dynamic tile queue (atomic pop per wave) mis-compiled into a non-terminating loop and
+// was removed.
+#ifndef BHR_TPW
+#define BHR_TPW 1
+#endif
+template <bool DIFF>
+__device__ __forceinline__ void march_tiles_of_wave(const BhrMarchArgs &a) {
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+#pragma unroll 1
+    for (int t = 0; t < BHR_TPW; ++t) {
+        const int slot = wave + t * n_waves;
+        if (slot < a.n_tiles) march_tile_body<DIFF, 0>(a, slot);
+    }
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void march_tile_plain_ilp(BhrMarchArgs a) { march_tiles_of_wave<false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void march_tile_aa_ilp(BhrMarchArgs a) { march_tiles_of_wave<true>(a); }
 #endif
 
 // ---------------------------------------------------------------------------
@@ -1211,6 +1240,14 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         BHR_HIP(hipMemsetAsync(ctx->d_row_steps, 0, n * sizeof(unsigned long long), ctx->stream));
         a.row_steps = ctx->d_row_steps;
     }
+    a.wave_stamps = nullptr;
+    const char *stamp_path = getenv("BHR_WAVE_STAMPS");     // diagnostic: dump per-wave start / end times of THIS launch
+    unsigned long long *d_stamps = nullptr;
+    if (stamp_path && stamp_path[0]) {
+        BHR_HIP(hipMalloc((void **)&d_stamps, (size_t)a.n_tiles * 4 * sizeof(unsigned long long)));
+        BHR_HIP(hipMemsetAsync(d_stamps, 0, (size_t)a.n_tiles * 4 * sizeof(unsigned long long), ctx->stream));
+        a.wave_stamps = d_stamps;
+    }
     a.tile_order = nullptr;
     {
         const char *e = getenv("BHR_TILE_ORDER");          // "centre" (default) | "row": row-major, for A/B runs
@@ -1245,10 +1282,13 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
             else
                 hipLaunchKernelGGL((march_tile_kernel<false, 1>), grid, block, 0, ctx->stream, a);
 #if BHR_MARCH_STRICT && BHR_MARCH_ILP
-        } else if (want_diff) {
-            hipLaunchKernelGGL(march_tile_aa_ilp, grid, block, 0, ctx->stream, a);
         } else {
-            hipLaunchKernelGGL(march_tile_plain_ilp, grid, block, 0, ctx->stream, a);
+            const int waves = (a.n_tiles + BHR_TPW - 1) / BHR_TPW;          // BHR_TPW tiles per wave
+            const dim3 g((waves + wpb - 1) / wpb);
+            if (want_diff)
+                hipLaunchKernelGGL(march_tile_aa_ilp, g, block, 0, ctx->stream, a);
+            else
+                hipLaunchKernelGGL(march_tile_plain_ilp, g, block, 0, ctx->stream, a);
         }
 #else
         } else if (want_diff) {
@@ -1272,6 +1312,13 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     }
     BHR_HIP(hipGetLastError());
     BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 1] : ctx->ev[1], ctx->stream));
+    if (d_stamps) {
+        std::vector<unsigned long long> h((size_t)a.n_tiles * 4);
+        BHR_HIP(hipMemcpyAsync(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        BHR_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_stamps);
+        if (FILE *f = fopen(stamp_path, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+    }
     ctx->last_steps_ptr = a.ray_steps;
     ctx->counters.rays = (uint64_t)c.width * ctx->rows;
     return BHR_OK;
