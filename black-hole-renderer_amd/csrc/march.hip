@@ -984,8 +984,10 @@ __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
 // shows 88-92 % slot occupancy in the body of an fhd launch and a ~90 us ragged end; blocks of 64 threads (4x the
 // workgroups) take 0.89 ms instead of 0.69, so the workgroup dispatcher matters -- but 2 / 3 / 4 tiles per wave do not
 // buy it back (0.696 / 0.717 / 0.726 ms against 0.679 at one; 1501 fps with two frames in flight at 2, 1498 at 1).
-// One tile per wave stays; a dynamic tile queue (atomic pop per wave) mis-compiled into a non-terminating loop and
-// was removed.
+// One tile per wave stays.  A dynamic tile queue (resident waves popping tiles from a counter) was tried twice: with a
+// data-dependent exit it compiled into a non-terminating loop, with a fixed trip count it ran correctly at 1.08-1.23 ms
+// whatever the grid (each wave is latency-bound at ~15 cycles per instruction, so fewer, longer-lived waves only
+// lengthen the critical path); both removed.
 #ifndef BHR_TPW
 #define BHR_TPW 1
 #endif
