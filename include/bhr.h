@@ -191,8 +191,11 @@ BHR_API int32_t bhr_eval_noise(bhr_ctx *ctx, const float *coords, int64_t n, int
 
 /* ---- the hot path: TaichiRenderer.render() (render.py:3865-3923) ----------
  * Launches the fused ray-march kernel for rows [row0,row1), then (unless
- * BHR_SKIP_BLOOM) the bloom H pass, V pass and final combine.  Asynchronous on
- * the context's stream; results stay in HBM until read. */
+ * BHR_SKIP_BLOOM) the bloom H pass, V pass and final combine.  Asynchronous; results stay
+ * in HBM until read.  Successive calls alternate between the context's two frame slots (own stream and frame
+ * buffers, shared read-only scene), so frame n + 1 overlaps the tail and the post-passes of frame n; every other
+ * entry point is ordered (on the device) behind the frames in flight: reads return the last frame rendered, scene
+ * updates never race a march.  BHR_FRAME_SLOTS=1 in the environment of bhr_create: one frame at a time. */
 BHR_API int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);
 /* image_field/disk_layer_field/blur_field .to_numpy() and the final image,
  * for the context's rows: (row1-row0, width, 3) f32.  Synchronises. */
