@@ -48,6 +48,9 @@
 #ifndef BHR_MARCH_ILP
 #define BHR_MARCH_ILP 0
 #endif
+#ifndef BHR_WAVE_STAMPS_BUILD
+#define BHR_WAVE_STAMPS_BUILD 0
+#endif
 #if BHR_MARCH_STRICT && BHR_MARCH_ILP
 // third compilation: the strict source scheduled with -mllvm -amdgpu-sched-strategy=max-ilp.  Its two texture kernels
 // are launched (march_tile_plain_ilp, march_tile_aa_ilp, each with its own occupancy target): the plain one gains 4 %
@@ -935,7 +938,9 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
     const int j = ty * 8 + (lane >> 3);
     const bool valid = tile < a.n_tiles && i < a.width && j < a.rows;
 
+#if BHR_WAVE_STAMPS_BUILD
     const unsigned long long t_start = a.wave_stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
     Ray<DIFF, SRC> ray;
     ray.init(a, valid ? i : 0, valid ? j : 0);
     if (!valid) ray.done = 4;
@@ -960,6 +965,7 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
         // BHR_ROW_COSTS: cost profile over tile rows = ray-steps + the wave's shading passes, each priced as
         // BHR_FLUSH_COST wave-steps (a pass is ~1000 instructions, a strict step ~220)
         if (a.row_steps && tile < a.n_tiles) atomicAdd(a.row_steps + ty, tot + (unsigned long long)flushes * (64u * BHR_FLUSH_COST));
+#if BHR_WAVE_STAMPS_BUILD
         if (a.wave_stamps && slot < a.n_tiles) {          // diagnostic: when this wave lived (100 MHz ticks) and what it did
             unsigned long long *w = a.wave_stamps + (size_t)slot * 4;
             w[0] = t_start;
@@ -967,6 +973,7 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
             w[2] = tot | ((unsigned long long)flushes << 40);
             w[3] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
         }
+#endif
     }
 }
 
@@ -1243,7 +1250,9 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         a.row_steps = ctx->d_row_steps;
     }
     a.wave_stamps = nullptr;
-    const char *stamp_path = getenv("BHR_WAVE_STAMPS");     // diagnostic: dump per-wave start / end times of THIS launch
+    // diagnostic (builds with -DBHR_WAVE_STAMPS_BUILD=1 only: the stamps cost the plain kernel three spilled registers):
+    // BHR_WAVE_STAMPS=<file> dumps per-wave start / end times of THIS launch (tools/wave_timeline.py)
+    const char *stamp_path = BHR_WAVE_STAMPS_BUILD ? getenv("BHR_WAVE_STAMPS") : nullptr;
     unsigned long long *d_stamps = nullptr;
     if (stamp_path && stamp_path[0]) {
         BHR_HIP(hipMalloc((void **)&d_stamps, (size_t)a.n_tiles * 4 * sizeof(unsigned long long)));

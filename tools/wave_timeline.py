@@ -1,5 +1,6 @@
 """Occupancy over time of one march launch from per-wave stamps (BHR_WAVE_STAMPS=<file>, csrc/march.hip):
-how long the launch runs at full occupancy, how long its ragged end is, what the last waves were doing."""
+how long the launch runs at full occupancy, how long its ragged end is, what the last waves were doing.
+Needs a diagnostic build of the library: make -C black-hole-renderer_amd/csrc EXTRA=-DBHR_WAVE_STAMPS_BUILD=1 (after touching march.hip)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
