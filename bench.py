@@ -309,11 +309,21 @@ def main():
                           "march_vgprs": c["march_vgprs"],
                           "how": "HIP events on the launching stream, isolated launches (one frame slot)"
                                  + ("" if iso is None else f", {iso['fps']:.0f} fps one frame at a time")},
-            "kernel_ms_in_timed_region": dict(overlapped, note="event brackets of overlapping launches (two frame slots): "
-                                              "each covers time shared with the other frame's kernels"),
+            "kernel_ms_in_timed_region": dict(overlapped, march_busy_ms=c["march_busy_ms"], span_ms=c["span_ms"],
+                                              note="event brackets of overlapping launches (two frame slots): each covers time shared "
+                                                   "with the other frame's kernels; march_busy_ms = union of the march intervals"),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "march", "algorithmic_bytes_per_launch": alg_bytes},
+            # the same two ratios over the TIMED REGION itself: all march launches of the region / the time during which
+            # at least one of them was running (union of their event brackets; launches of successive frames overlap)
+            "roofline_in_timed_region": {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "achieved": alg_bytes * n_frames / (c["march_busy_ms"] * 1e-3) / 1e9 if c["march_busy_ms"] > 0 else None,
+                "frac": alg_bytes * n_frames / (c["march_busy_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if c["march_busy_ms"] > 0 else None,
+                "valu_tflops": MARCH_FLOP_PER_RAY_STEP * c["ray_steps_sum"] / (c["march_busy_ms"] * 1e-3) / 1e12 if c["march_busy_ms"] > 0 else None,
+                "valu_frac": MARCH_FLOP_PER_RAY_STEP * c["ray_steps_sum"] / (c["march_busy_ms"] * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS if c["march_busy_ms"] > 0 else None,
+                "march_launches": n_frames, "march_busy_ms": c["march_busy_ms"]},
             # the march is not HBM bound: the governing ceiling is non-matrix FP32
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_FP32_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": valu_tflops / VALU_FP32_PEAK_TFLOPS,

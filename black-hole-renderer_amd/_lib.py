@@ -48,7 +48,8 @@ class Counters(C.Structure):
     _fields_ = [("ray_steps", C.c_uint64), ("rays", C.c_uint64), ("march_ms", C.c_float), ("bloom_ms", C.c_float),
                 ("frame_ms", C.c_float), ("background_ms", C.c_float), ("compose_ms", C.c_float),
                 ("march_vgprs", C.c_int32), ("march_lds_bytes", C.c_int32), ("frames_timed", C.c_int32),
-                ("march_ms_sum", C.c_float), ("bloom_ms_sum", C.c_float), ("ray_steps_sum", C.c_uint64)]
+                ("march_ms_sum", C.c_float), ("bloom_ms_sum", C.c_float), ("ray_steps_sum", C.c_uint64),
+                ("march_busy_ms", C.c_float), ("span_ms", C.c_float)]
 
 
 class BhrError(RuntimeError):

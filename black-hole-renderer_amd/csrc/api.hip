@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "bhr_internal.h"
@@ -638,6 +640,28 @@ int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {
                 steps_sum += hs[slot];
             }
         }
+        // union of the march intervals, on the clock of the oldest timed frame's start event (events of the two
+        // slot streams are comparable: hipEventElapsedTime works across streams of one device)
+        float busy = 0.0f, span = 0.0f;
+        if (n > 0) {
+            const int first = (int)((ctx->ring_head - n) % BHR_TIMING_RING);
+            const hipEvent_t origin = ctx->ring_ev[first * 3 + 0];
+            std::vector<std::pair<float, float>> iv((size_t)n);
+            for (int64_t k = 0; k < n; ++k) {
+                const int slot = (int)((ctx->ring_head - n + k) % BHR_TIMING_RING);
+                iv[(size_t)k] = {ev_ms(origin, ctx->ring_ev[slot * 3 + 0]), ev_ms(origin, ctx->ring_ev[slot * 3 + 1])};
+                span = std::max(span, ev_ms(origin, ctx->ring_ev[slot * 3 + 2]));
+            }
+            std::sort(iv.begin(), iv.end());
+            float lo = iv[0].first, hi = iv[0].second;
+            for (size_t k = 1; k < iv.size(); ++k) {
+                if (iv[k].first > hi) { busy += hi - lo; lo = iv[k].first; hi = iv[k].second; }
+                else hi = std::max(hi, iv[k].second);
+            }
+            busy += hi - lo;
+        }
+        ctx->counters.march_busy_ms = busy;
+        ctx->counters.span_ms = span;
         ctx->counters.frames_timed = (int32_t)n;
         ctx->counters.march_ms_sum = ms_m;
         ctx->counters.bloom_ms_sum = ms_b;

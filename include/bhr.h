@@ -119,6 +119,11 @@ typedef struct {
     float march_ms_sum;
     float bloom_ms_sum;
     uint64_t ray_steps_sum;  /* ray_steps of one frame x frames_timed is NOT assumed: summed per frame */
+    /* With two frames in flight the march launches of successive frames overlap, so march_ms_sum counts shared time
+     * twice.  march_busy_ms = length of the UNION of the timed frames' [march start, march end] intervals: the time
+     * during which at least one march kernel of this context was running; span_ms = first march start .. last frame end. */
+    float march_busy_ms;
+    float span_ms;
 } bhr_counters;
 
 #define BHR_TIMING_RING 512

@@ -113,3 +113,24 @@ def test_persistent_schedule_and_row_costs_stay_exclusive(hip_lib):
     np.testing.assert_array_equal(two.row_costs(cam, fov), one.row_costs(cam, fov))
     one.close()
     two.close()
+
+
+@pytest.mark.parametrize("slots", [1, 2])
+def test_march_busy_time_is_the_union_of_the_march_intervals(slots, hip_lib):
+    """bhr_counters.march_busy_ms: with one frame at a time it equals the sum of the march brackets; with two frames in
+    flight it is at most that sum (shared time counted once) and at most the span of the timed frames."""
+    r = _mk(slots, w=1920, h=1080)
+    cam, fov = CAMS[0]
+    for _ in range(5):
+        r.render_async(cam, fov)
+    r.timing_reset()
+    for _ in range(40):
+        r.render_async(cam, fov)
+    c = r.counters()
+    assert c["frames_timed"] == 40 and c["march_busy_ms"] > 0 and c["span_ms"] >= c["march_busy_ms"] * 0.999
+    if slots == 1:
+        assert abs(c["march_busy_ms"] - c["march_ms_sum"]) <= 1e-3 * c["march_ms_sum"] + 1e-3
+    else:
+        assert c["march_busy_ms"] <= c["march_ms_sum"] * 1.001
+        assert c["march_busy_ms"] < 0.98 * c["march_ms_sum"]         # the launches really overlap
+    r.close()
