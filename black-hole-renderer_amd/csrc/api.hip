@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <utility>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "bhr_internal.h"
@@ -738,14 +740,36 @@ int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint3
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     const size_t R = ctxs[0]->bloom_R;
 
-    // phase 1: every tile marches and H-blurs its own rows, concurrently
-    for (int k = 0; k < n; ++k) {
+    // phase 1: every tile marches and H-blurs its own rows, concurrently.  With several devices the launches are
+    // submitted by one host thread per tile: a single thread needs ~30 us per device (hipSetDevice + memset + three
+    // launches + events), which at 8 devices starts the last march a quarter of a millisecond late in a 3 ms frame.
+    auto phase1 = [&](int k) -> int32_t {
         BHR_TRY(use_device(ctxs[k]));
         ctxs[k]->cur_slot = -1;
         ctxs[k]->last_slot = -1;
         BHR_TRY(bhr_launch_march(ctxs[k], cam, flags));
         if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctxs[k]));
         BHR_HIP(hipEventRecord(ctxs[k]->ev[3], ctxs[k]->stream));
+        return BHR_OK;
+    };
+    bool distinct_devices = n > 1;
+    for (int k = 1; k < n && distinct_devices; ++k)
+        for (int q = 0; q < k; ++q)
+            if (ctxs[k]->cfg.device == ctxs[q]->cfg.device) distinct_devices = false;
+    if (const char *e = getenv("BHR_GROUP_THREADS")) distinct_devices = n > 1 && atoi(e) != 0;   // test knob: force / forbid
+    if (distinct_devices) {
+        std::vector<int32_t> rcs((size_t)n, BHR_OK);
+        std::vector<std::string> errs((size_t)n);
+        std::vector<std::thread> th;
+        for (int k = 1; k < n; ++k)
+            th.emplace_back([&, k] { rcs[(size_t)k] = phase1(k); if (rcs[(size_t)k] != BHR_OK) errs[(size_t)k] = bhr_last_error(); });
+        rcs[0] = phase1(0);
+        if (rcs[0] != BHR_OK) errs[0] = bhr_last_error();
+        for (auto &t : th) t.join();
+        for (int k = 0; k < n; ++k)
+            if (rcs[(size_t)k] != BHR_OK) return bhr_fail(rcs[(size_t)k], "tile %d: %s", k, errs[(size_t)k].c_str());
+    } else {
+        for (int k = 0; k < n; ++k) BHR_TRY(phase1(k));
     }
     // phase 2: halo exchange of the H-blurred rows (planar (3, rows + 2R, W)); the V pass of
     // tile k needs up to R rows from each neighbour.  Peer copies ride the receiving stream

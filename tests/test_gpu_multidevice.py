@@ -76,3 +76,19 @@ def test_make_tiles_cost_balanced_blocks(hip_lib):
     np.testing.assert_allclose(got, one.render(wl["cam_pos"], wl["fov"]), atol=1e-6, rtol=0)
     for t in tiles + [one]:
         t.close()
+
+
+def test_threaded_submission_gives_the_same_frame(hip_lib, monkeypatch):
+    """With distinct devices bhr_group_render submits each tile's march from its own host thread; forced here on one
+    device (BHR_GROUP_THREADS=1) so that the path runs on the test box: the frame must not change."""
+    from bhr_amd import multigpu
+    s, tiles, full = _tiles([0, 50, 54, 120, 180], [0, 0, 0, 0])
+    monkeypatch.setenv("BHR_GROUP_THREADS", "0")
+    want = multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="host")
+    monkeypatch.setenv("BHR_GROUP_THREADS", "1")
+    for _ in range(5):
+        np.testing.assert_array_equal(multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="host"), want)
+        multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="peer")
+        np.testing.assert_array_equal(multigpu.read_gathered(tiles), want)
+    for t in tiles + [full]:
+        t.close()
