@@ -123,3 +123,27 @@ def test_render_video_writes_the_stream(tmp_path):
         np.testing.assert_array_equal(y, wy)
         np.testing.assert_array_equal(cb, wcb)
         np.testing.assert_array_equal(cr, wcr)
+
+
+def test_render_video_pipes_the_stream_into_ffmpeg(tmp_path, monkeypatch):
+    """video_stream="auto" with an `ffmpeg` on PATH: the frames reach the encoder's stdin as one YUV4MPEG2 stream while
+    they render, and no PNG is read back.  The image has no ffmpeg, so a stand-in that stores its stdin in the output
+    file plays the encoder (what is under test is the pipe, not libx264)."""
+    import stat
+    from bhr_amd import drivers
+    from bhr_amd.output import read_y4m
+    fake = tmp_path / "bin" / "ffmpeg"
+    fake.parent.mkdir()
+    fake.write_text('#!/bin/sh\nfor a in "$@"; do out="$a"; done\ncat > "$out"\n')
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(fake.parent) + os.pathsep + os.environ["PATH"])
+    out = str(tmp_path / "vid" / "v.mp4")
+    r, _, _, _ = drivers.make_renderer(160, 90, [6, 0, 0.5], 90, n_stars=50, tex_w=256, tex_h=128)
+    drivers.render_video(r, 160, 90, n_frames=7, fps=30, output_path=out, fov=90, static_cam_pos=[6, 0, 0.5], orbit=True,
+                         orbit_degrees=45.0, assemble=True, video_stream="auto")
+    r.close()
+    head, planes = read_y4m(out)                      # the stand-in wrote the stream it was given
+    assert (head["width"], head["height"], head["fps"]) == (160, 90, "30:1") and len(planes) == 7
+    assert all(p[0].max() > 40 for p in planes)
+    d = drivers._frames_dir(out)
+    assert sorted(f for f in os.listdir(d) if f.endswith(".png")) == [f"frame_{k:04d}.png" for k in range(7)]
