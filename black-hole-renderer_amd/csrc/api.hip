@@ -51,13 +51,18 @@ int32_t alloc_slot(bhr_ctx *ctx, int k) {
         else BHR_HIP(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
     }
     if (!f.done) BHR_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
-    BHR_TRY(dev_alloc(&f.d_bg, px3));
-    BHR_TRY(dev_alloc(&f.d_disk, px3));
-    BHR_TRY(dev_alloc(&f.d_blur, px3));
-    BHR_TRY(dev_alloc(&f.d_final, px3));
-    BHR_TRY(dev_alloc(&f.d_final_u8, px3));
-    BHR_TRY(dev_alloc(&f.d_hblur, 3 * (rows + 2 * R) * W));
-    BHR_TRY(dev_alloc(&f.d_queue, 1));
+    int32_t rc = BHR_OK;
+    if ((rc = dev_alloc(&f.d_bg, px3)) || (rc = dev_alloc(&f.d_disk, px3)) || (rc = dev_alloc(&f.d_blur, px3)) ||
+        (rc = dev_alloc(&f.d_final, px3)) || (rc = dev_alloc(&f.d_final_u8, px3)) ||
+        (rc = dev_alloc(&f.d_hblur, 3 * (rows + 2 * R) * W)) || (rc = dev_alloc(&f.d_queue, 1))) {
+        void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur, f.d_queue};   // a later retry starts clean
+        for (void *b : bufs)
+            if (b) (void)hipFree(b);
+        f.d_bg = f.d_disk = f.d_blur = f.d_final = f.d_hblur = nullptr;
+        f.d_final_u8 = nullptr;
+        f.d_queue = nullptr;
+        return rc;
+    }
     // the halo rows of the H-blur buffer outside the image stay zero for the life of the context
     BHR_HIP(hipMemsetAsync(f.d_hblur, 0, 3 * (rows + 2 * R) * W * sizeof(float), ctx->scene_stream));
     BHR_HIP(hipStreamSynchronize(ctx->scene_stream));

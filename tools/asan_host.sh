@@ -8,7 +8,7 @@ OUT=/tmp/bhr_asan
 mkdir -p $OUT
 cd $ROOT/black-hole-renderer_amd/csrc
 make -s
-for f in api output flare lifecycle api_disk_v2 disk_v2 bloom texture; do
+for f in api output flare lifecycle api_disk_v2 disk_v2 bloom texture skyglow; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -DBHR_BUILD -fsanitize=address \
       -fno-omit-frame-pointer -Wno-option-ignored -c $f.hip -o $OUT/$f.o &
 done
