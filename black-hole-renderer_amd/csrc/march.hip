@@ -511,8 +511,6 @@ struct Ray {
     int step_count;
     int pix;       // linear pixel index inside the row block, -1 = lane has no ray
     int done;      // 0 running, 1 captured, 2 escaped, 3 ran out of iterations, 4 empty lane
-    V3 esc;        // new_dir of an escaped ray (kRedo only; otherwise it is d)
-    Pending<DIFF> pendr;   // kRedo: the single parked crossing stays in registers
     V3 dpx, ddx, dpy, ddy;   // ray differentials (DIFF only)
 
     __device__ __forceinline__ void init(const BhrMarchArgs &a, int i, int j_local) {
@@ -531,7 +529,6 @@ struct Ray {
         n_pend = 0;
         step_count = 0;
         done = a.max_iter <= 0 ? 3 : 0;
-        esc = mk(0, 0, 0);
         pix = j_local * a.width + i;
         if (DIFF) {
             dpx = mk(0, 0, 0);
@@ -552,14 +549,11 @@ struct Ray {
                   div6(fmaf(2.0f, k3.z, fmaf(2.0f, k2.z, k1.z)) + k4.z));
     }
 
-    // One iteration of the while-loop at render.py:2854-3006; false = nothing committed, repeat the step.
-    // Without differentials the state is committed unconditionally: a lane whose ray has terminated leaves
-    // the loop and never reads it again (escaped rays read d = new_dir), and with two parking slots a hit
-    // always finds room.  With differentials (128 VGPRs, at the edge of 4 waves per SIMD) the measured
-    // optimum is the opposite: ONE slot, a lane that finds it occupied returns false, the wave shades what
-    // is parked and the lane repeats its deterministic step; the guarded commit also keeps the scheduler
-    // from stretching live ranges across the whole step (4k AA: 6.7 ms against 7.6 ms unconditional).
-    static constexpr bool kRedo = DIFF;
+    // One iteration of the while-loop at render.py:2854-3006.  The state is committed unconditionally: a lane whose ray
+    // has terminated leaves the loop and never reads it again (escaped rays read d = new_dir), and with two parking slots
+    // in LDS a hit always finds room, with or without differentials.  (Until round 2 the AA kernel kept ONE slot in
+    // registers and repeated the step of a lane that found it occupied; under the ILP scheduler at 4 waves per SIMD the
+    // LDS scheme is 3 % faster -- 4k AA 6.44 -> 6.26 ms, same pixels -- and the redo path is gone.)
     __device__ __forceinline__ bool step(const BhrMarchArgs &a) {
         // clamps as single v_med3 / v_min instructions (no NaN can reach them: r is a finite norm); the C forms cost a
         // canonicalising v_max, and compare + select pairs
@@ -643,36 +637,18 @@ struct Ray {
                 // the differentials were committed BEFORE the hit interpolation (render.py:2928-2932),
                 // hence hit_d_pos == new_d_pos in render.py:2947-2949
                 if (DIFF) { h.dxx = ndpx.x; h.dxy = ndpx.y; h.dyx = ndpy.x; h.dyy = ndpy.y; }
-                if (kRedo) {
-                    if (n_pend == 1) return false;            // slot occupied: flush, then repeat this step
-                    pendr = h;
-                } else {
-                    park_store<DIFF>(n_pend, h);              // a free slot is guaranteed (march_tile_kernel)
-                }
+                park_store<DIFF>(n_pend, h);                  // a free slot is guaranteed (march_tile_body flushes at 2)
                 n_pend += 1;
             }
         }
         affine = aff;
-        if (kRedo) {
-            // the guarded commit of the single-slot scheme (see above); escaped rays keep new_dir in esc
-            if (escaped) esc = nd;
-            if (alive) {
-                if (DIFF) { dpx = ndpx; ddx = nddx; dpy = ndpy; ddy = nddy; }
-                p = np;
-                d = nd;
-                r = rn;
-                r2p = r2n;
-                f_old = f_new;
-                step_count += 1;
-            }
-        } else {
-            p = np;
-            d = nd;
-            r = rn;
-            r2p = r2n;
-            f_old = f_new;
-            step_count += 1;
-        }
+        if (DIFF) { dpx = ndpx; ddx = nddx; dpy = ndpy; ddy = nddy; }
+        p = np;
+        d = nd;
+        r = rn;
+        r2p = r2n;
+        f_old = f_new;
+        step_count += 1;
         done = captured ? 1 : (escaped ? 2 : (step_count >= a.max_iter ? 3 : 0));
         return true;
     }
@@ -680,13 +656,13 @@ struct Ray {
     // shade the oldest parked crossing (lanes that have one), the second slot moves up
     __device__ __forceinline__ void flush_one(const BhrMarchArgs &a) {
         if (n_pend > 0) {
-            const Pending<DIFF> h = kRedo ? pendr : park_load<DIFF>(0);
-            if (!kRedo && n_pend == 2) park_store<DIFF>(0, park_load<DIFF>(1));
+            const Pending<DIFF> h = park_load<DIFF>(0);
+            if (n_pend == 2) park_store<DIFF>(0, park_load<DIFF>(1));
             n_pend -= 1;
             shade_hit<DIFF, SRC>(a, sh, h.hit_x, h.hit_y, h.to_cam, h.dxx, h.dxy, h.dyx, h.dyy);
         }
     }
-    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, kRedo ? esc : d, sh); }
+    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, d, sh); }
 };
 
 #else
