@@ -210,7 +210,14 @@ struct bhr_sink {
     bhr_ctx *ctx = nullptr;
     int w = 0, h = 0, level = 1;
     size_t frame_bytes = 0;
-    struct Slot { uint8_t *host = nullptr; hipEvent_t ev = nullptr; };
+    bool on_device = false;        // level BHR_PNG_DEVICE: the slot receives finished PNG bytes (png_device.hip)
+    size_t host_bytes = 0;         // size of a slot's pinned buffer: the raw frame, or the bound of the device encoder
+    struct Slot {
+        uint8_t *host = nullptr;
+        hipEvent_t ev = nullptr;
+        uint8_t *dev = nullptr;    // device encoder: PNG bytes in HBM
+        uint32_t *d_meta = nullptr, *h_meta = nullptr;   // {length, error, ..}: device, and its pinned copy
+    };
     std::vector<Slot> slots;
     std::deque<int> free_slots;
     struct Job { int slot; std::string path; };
@@ -226,22 +233,37 @@ struct bhr_sink {
 
     void work() {
         (void)hipSetDevice(ctx->cfg.device);
-        std::vector<uint8_t> png((size_t)bhr_png_bound(w, h));
+        std::vector<uint8_t> png(on_device ? 0 : (size_t)bhr_png_bound(w, h));
+        hipStream_t copy_stream = nullptr;          // device encoder: each worker fetches exactly the bytes of its file
+        if (on_device) (void)hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
         for (;;) {
             Job job;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv_job.wait(lk, [&] { return stop || !jobs.empty(); });
-                if (jobs.empty()) return;
+                if (jobs.empty()) break;
                 job = jobs.front();
                 jobs.pop_front();
             }
             int32_t rc = BHR_OK;
             int64_t len = 0;
-            const hipError_t e = hipEventSynchronize(slots[job.slot].ev);
+            Slot &sl = slots[job.slot];
+            hipError_t e = hipEventSynchronize(sl.ev);
             if (e != hipSuccess) rc = bhr_fail(BHR_ERR_HIP, "frame sink: hipEventSynchronize: %s", hipGetErrorString(e));
-            if (rc == BHR_OK) rc = encode_png(slots[job.slot].host, w, h, level, 1, png.data(), (int64_t)png.size(), &len);
-            if (rc == BHR_OK) rc = write_file_atomic(job.path.c_str(), png.data(), (size_t)len);
+            if (on_device) {
+                if (rc == BHR_OK && (sl.h_meta[1] != 0 || sl.h_meta[0] > host_bytes))
+                    rc = bhr_fail(BHR_ERR_STATE, "frame sink: the device encoder overran its bound (%u bytes)", sl.h_meta[0]);
+                if (rc == BHR_OK) {
+                    len = (int64_t)sl.h_meta[0];
+                    e = copy_stream ? hipMemcpyAsync(sl.host, sl.dev, (size_t)len, hipMemcpyDeviceToHost, copy_stream) : hipErrorUnknown;
+                    if (e == hipSuccess) e = hipStreamSynchronize(copy_stream);
+                    if (e != hipSuccess) rc = bhr_fail(BHR_ERR_HIP, "frame sink: fetching the encoded frame: %s", hipGetErrorString(e));
+                }
+                if (rc == BHR_OK) rc = write_file_atomic(job.path.c_str(), sl.host, (size_t)len);
+            } else {
+                if (rc == BHR_OK) rc = encode_png(sl.host, w, h, level, 1, png.data(), (int64_t)png.size(), &len);
+                if (rc == BHR_OK) rc = write_file_atomic(job.path.c_str(), png.data(), (size_t)len);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (rc != BHR_OK && err == BHR_OK) { err = rc; err_text = bhr_last_error(); }
@@ -252,6 +274,7 @@ struct bhr_sink {
             cv_free.notify_one();
             cv_idle.notify_all();
         }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
 };
 
@@ -457,7 +480,7 @@ int32_t bhr_png_write(const char *path, const uint8_t *rgb, int32_t w, int32_t h
 }
 
 int32_t bhr_sink_create(bhr_ctx *ctx, int32_t slots, int32_t workers, int32_t level, bhr_sink **out) {
-    if (!ctx || !out || slots < 1 || slots > 256 || workers < 1 || workers > 256 || level < 0 || level > 9)
+    if (!ctx || !out || slots < 1 || slots > 256 || workers < 1 || workers > 256 || level < BHR_PNG_DEVICE || level > 9)
         return bhr_fail(BHR_ERR_INVALID, "bhr_sink_create: bad argument (slots %d, workers %d, level %d)", slots, workers, level);
     BHR_HIP(hipSetDevice(ctx->cfg.device));
     bhr_sink *s = new bhr_sink();
@@ -465,11 +488,18 @@ int32_t bhr_sink_create(bhr_ctx *ctx, int32_t slots, int32_t workers, int32_t le
     s->w = ctx->cfg.width;
     s->h = ctx->rows;
     s->level = level;
+    s->on_device = level == BHR_PNG_DEVICE;
     s->frame_bytes = (size_t)s->w * s->h * 3;
+    s->host_bytes = s->on_device ? (size_t)bhr_png_device_bound(s->w, s->h) : s->frame_bytes;
     s->slots.resize(slots);
     for (int k = 0; k < slots; ++k) {
-        hipError_t e = hipHostMalloc((void **)&s->slots[k].host, s->frame_bytes, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc((void **)&s->slots[k].host, s->host_bytes, hipHostMallocDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->slots[k].ev, hipEventDisableTiming);
+        if (e == hipSuccess && s->on_device) {
+            e = hipMalloc((void **)&s->slots[k].dev, s->host_bytes);
+            if (e == hipSuccess) e = hipMalloc((void **)&s->slots[k].d_meta, 4 * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipHostMalloc((void **)&s->slots[k].h_meta, 4 * sizeof(uint32_t), hipHostMallocDefault);
+        }
         if (e != hipSuccess) {
             bhr_sink_destroy(s);
             return bhr_fail(BHR_ERR_HIP, "bhr_sink_create: %s", hipGetErrorString(e));
@@ -495,7 +525,14 @@ int32_t bhr_sink_submit(bhr_sink *s, const char *path) {
     hipError_t e = hipSuccess;
     int32_t rc = bhr_enter(ctx);            // the scene stream follows the frame in flight; quantise + copy queue behind it
     if (rc == BHR_OK) rc = bhr_launch_quantize(ctx);
-    if (rc == BHR_OK) {
+    if (rc == BHR_OK && s->on_device) {
+        bhr_sink::Slot &sl = s->slots[slot];
+        rc = bhr_launch_png_encode(ctx, ctx->d_final_u8, sl.dev, (int64_t)s->host_bytes, sl.d_meta);
+        if (rc == BHR_OK) {
+            e = hipMemcpyAsync(sl.h_meta, sl.d_meta, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipEventRecord(sl.ev, ctx->stream);
+        }
+    } else if (rc == BHR_OK) {
         e = hipMemcpyAsync(s->slots[slot].host, ctx->d_final_u8, s->frame_bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(s->slots[slot].ev, ctx->stream);
     }
@@ -542,6 +579,9 @@ void bhr_sink_destroy(bhr_sink *s) {
     for (auto &sl : s->slots) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
         if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.d_meta) (void)hipFree(sl.d_meta);
+        if (sl.h_meta) (void)hipHostFree(sl.h_meta);
     }
     delete s;
 }

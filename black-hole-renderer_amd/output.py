@@ -15,6 +15,7 @@ from . import _lib
 
 DEFAULT_LEVEL = 6          # PIL's default zlib level for PNG
 VIDEO_LEVEL = 1            # frames that are re-encoded into an MP4 anyway
+DEVICE = -1                # BHR_PNG_DEVICE: filter + Huffman-code the frame on the GPU (csrc/png_device.hip)
 
 
 def _u8(a: np.ndarray) -> np.ndarray:
@@ -48,6 +49,31 @@ def png_write(path: str, rgb_u8: np.ndarray, level: int = DEFAULT_LEVEL, threads
     _lib.check(_lib.load().bhr_png_write(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, level, threads))
 
 
+def png_encode_device(renderer) -> bytes:
+    """PNG file bytes of the renderer's FINAL layer, filtered and entropy coded on the device (bhr_png_encode_device)."""
+    lib = _lib.load()
+    cap = lib.bhr_png_device_bound(renderer.width, renderer.rows)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_int64(0)
+    _lib.check(lib.bhr_png_encode_device(renderer._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def png_device_menu():
+    """The encoder's code menu: list of (codes[257] uint32 = reversed code << 4 | length, header words, header bits)."""
+    lib = _lib.load()
+    n = C.c_int32(0)
+    U32P = C.POINTER(C.c_uint32)
+    out, k = [], 0
+    while True:
+        codes, hdr, bits = np.zeros(257, np.uint32), np.zeros(64, np.uint32), C.c_uint32(0)
+        _lib.check(lib.bhr_png_device_menu(k, codes.ctypes.data_as(U32P), hdr.ctypes.data_as(U32P), C.byref(bits), C.byref(n)))
+        out.append((codes, hdr, int(bits.value)))
+        k += 1
+        if k >= n.value:
+            return out
+
+
 def quantize(image: np.ndarray) -> np.ndarray:
     """save_image's 8-bit conversion: truncation, not rounding (render.py:423)."""
     return (np.clip(image, 0, 1) * 255).astype(np.uint8)
@@ -57,7 +83,8 @@ class FrameSink:
     """Device frame -> PNG file without stalling the render stream.
 
     ``submit(path)`` quantises the renderer's FINAL layer on the device, starts the copy into a pinned
-    host slot and returns; worker threads encode and write.  ``drain()`` waits for the files."""
+    host slot and returns; worker threads encode and write.  ``drain()`` waits for the files.
+    ``level=DEVICE`` encodes on the GPU as well: the workers only fetch the finished bytes and write them."""
 
     def __init__(self, renderer, slots: int = 0, workers: int = 0, level: int = VIDEO_LEVEL):
         if workers <= 0:

@@ -23,6 +23,25 @@ BHR_API int32_t bhr_png_encode(const uint8_t *rgb, int32_t w, int32_t h, int32_t
 /* Image.fromarray(rgb).save(path): encode and write atomically (path.tmp, then rename). */
 BHR_API int32_t bhr_png_write(const char *path, const uint8_t *rgb, int32_t w, int32_t h, int32_t level, int32_t threads);
 
+/* PNG encoding on the device (csrc/png_device.hip).  The frame is filtered (the five PNG filters, the minimum sum of
+ * absolute residuals per scanline) and entropy coded in HBM: one dynamic-Huffman deflate block and one IDAT chunk per
+ * scanline, the prefix code of each scanline picked from a menu of 16 static codes (no LZ77 matches), chunk CRC-32 and
+ * stream Adler-32 computed on the device.  Any PNG reader decodes the result to exactly the pixels of
+ * bhr_read_final_u8; the files are ~15-25 % larger than zlib level 1 makes them and cost a fraction of a millisecond
+ * of device time instead of ~50 ms of a host core per fhd frame.  Replaces the same reference code as the host
+ * encoder (render.py:420-425, 4412-4467).
+ *   bhr_png_device_bound: capacity that always suffices for a w x h frame.
+ *   bhr_png_encode_device: quantise the context's FINAL layer and encode it; `out` (host) receives the file bytes.
+ *   BHR_PNG_DEVICE as the `level` of bhr_sink_create: the sink encodes on the device, its workers only fetch the
+ *     finished bytes (an exact-length copy on their own stream) and write the file. */
+#define BHR_PNG_DEVICE (-1)
+BHR_API int64_t bhr_png_device_bound(int32_t w, int32_t h);
+BHR_API int32_t bhr_png_encode_device(bhr_ctx *ctx, uint8_t *out, int64_t cap, int64_t *out_len);
+/* Entry k of the code menu, as the kernels use it (host only, no GPU needed; for inspection and tests):
+ * codes[257] = (bit-reversed code << 4) | length for literals 0..255 and end-of-block, hdr_words[64] / *hdr_bits =
+ * the deflate block header announcing that code, LSB first.  *n_tables receives the menu size. */
+BHR_API int32_t bhr_png_device_menu(int32_t k, uint32_t *codes, uint32_t *hdr_words, uint32_t *hdr_bits, int32_t *n_tables);
+
 /* Frame sink.  bhr_sink_submit quantises the context's FINAL layer on the device (save_image's
  * truncation), starts an asynchronous copy into one of `slots` pinned host buffers and returns; `workers`
  * host threads wait for the copy, encode and write `path`.  The caller goes on to render the next frame
