@@ -54,6 +54,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--video_stream", type=str, default="auto", choices=["auto", "y4m", "off"],
                    help="--video: also hand the frames to the encoder as a yuv420p stream converted on the device "
                         "(auto: pipe into ffmpeg when it is on PATH; y4m: write <output stem>.y4m; off: PNG frames only)")
+    p.add_argument("--png_encoder", type=str, default="device", choices=["device", "host"],
+                   help="--video: PNG frames are filtered and Huffman-coded on the GPU (device, default) or by zlib on "
+                        "host threads (host: ~10 %% smaller files, ~50 ms of a core per fhd frame)")
     p.add_argument("--ignore_taichi_cache", action="store_true", help="accepted for compatibility; no effect")
     p.add_argument("--video", action="store_true", help="render frames and assemble a video")
     p.add_argument("--interactive", action="store_true", help="not available in this build (needs ti.GUI)")
@@ -120,7 +123,8 @@ def main(argv=None) -> int:
         drivers.render_video(renderer, width, height, n_frames=args.n_frames, fps=args.fps,
                              output_path=args.output, fov=fov, static_cam_pos=args.pov, orbit=args.orbit,
                              resume=args.resume, disk_rotation_speed=args.disk_rotation_speed,
-                             orbit_degrees=args.orbit_degrees, rank=rank, world=world, video_stream=args.video_stream)
+                             orbit_degrees=args.orbit_degrees, rank=rank, world=world, video_stream=args.video_stream,
+                             png_level=(drivers.DEVICE if args.png_encoder == "device" else drivers.VIDEO_LEVEL))
         if world > 1:
             from . import distributed as D
             dist = D.init("gloo")          # a barrier is all the ranks exchange: frames are independent

@@ -291,6 +291,7 @@ void bhr_destroy(bhr_ctx *ctx) {
     free_bg(ctx);
     for (int k = 0; k < BHR_MAX_FRAME_SLOTS; ++k) free_slot(ctx, k);
     bhr_png_dev_free(ctx);
+    bhr_population_free(ctx);
     if (ctx->scene_ev) (void)hipEventDestroy(ctx->scene_ev);
     void *bufs[] = {ctx->d_skybox,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_noise_in,

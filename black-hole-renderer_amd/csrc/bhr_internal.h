@@ -167,6 +167,7 @@ struct bhr_ctx {
     double *d_flare_sums;      // S0, S1, S2
     float *d_gather;           // (H, W, 3): full frame gathered from the tiles of a group render (BHR_GATHER_PEER), on tile 0
     void *png_dev;             // device PNG encoder state (png_device.hip), created on first use
+    void *pop_host;            // pinned staging of bhr_accumulate_population (lifecycle.hip)
     float *h_pinned;           // staging for readbacks
     size_t h_pinned_bytes;
 
@@ -212,6 +213,7 @@ int32_t bhr_launch_quantize(bhr_ctx *ctx);                           // api.hip:
 // png_device.hip: (rows, W, 3) u8 at d_rgb -> PNG file bytes at d_out on ctx->stream; d_meta (4 words) = {length, error, ..}
 int32_t bhr_launch_png_encode(bhr_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_out, int64_t cap, uint32_t *d_meta);
 void bhr_png_dev_free(bhr_ctx *ctx);
+void bhr_population_free(bhr_ctx *ctx);                              // lifecycle.hip
 int32_t bhr_launch_build_mips(bhr_ctx *ctx);
 int32_t bhr_launch_background(bhr_ctx *ctx, float t);
 int32_t bhr_launch_compose(bhr_ctx *ctx, float t_offset, int32_t enable_rt, float color_temp);

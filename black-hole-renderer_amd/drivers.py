@@ -21,7 +21,7 @@ import numpy as np
 
 from .camera import orbit_position
 from .lifecycle import make_factories
-from .output import Y4MStream, FrameSink, VIDEO_LEVEL, png_write, quantize
+from .output import Y4MStream, FrameSink, VIDEO_LEVEL, DEVICE, png_write, quantize
 from .renderer import HipRenderer, R_DISK_INNER_DEFAULT, R_DISK_OUTER_DEFAULT
 from .skybox import load_or_generate_skybox
 from .textures import compute_disk_texture_resolution, load_disk_texture
@@ -174,7 +174,7 @@ def assemble_video(temp_dir: str, n_frames: int, fps: int, output_path: str) -> 
 def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, fps: int, output_path: str,
                  fov: float, static_cam_pos: List[float], orbit: bool = False, resume: bool = False,
                  disk_rotation_speed: float = 0.1, orbit_degrees: float = 360.0, rank: int = 0, world: int = 1,
-                 assemble: bool = True, png_level: int = VIDEO_LEVEL, sink_slots: int = 0, sink_workers: int = 0,
+                 assemble: bool = True, png_level: int = DEVICE, sink_slots: int = 0, sink_workers: int = 0,
                  video_stream: str = "auto", **_deprecated_kwargs) -> None:
     """N frames -> PNGs (+ MP4) (render.py:4356-4511).  Frame f is rendered by rank f % world.
 
@@ -183,7 +183,11 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
     stream converted on the device (output.Y4MStream): "auto" pipes it into ``ffmpeg -f yuv4mpegpipe`` when an
     ffmpeg binary is on PATH (MP4 written while the frames render; otherwise PNGs + assemble_video as before),
     "y4m" writes ``<output stem>.y4m`` beside the output, "off" never streams.  PNG frames and progress.json are
-    written in every mode (resume format of the reference)."""
+    written in every mode (resume format of the reference).
+
+    ``png_level``: output.DEVICE (default) filters and Huffman-codes every frame on the GPU (csrc/png_device.hip; the
+    sink's threads only fetch and write the finished files); 0..9 selects the host encoder at that zlib level
+    (smaller files, ~50 ms of a host core per fhd frame at level 1)."""
     os.makedirs(os.path.dirname(output_path) or ".", exist_ok=True)
     temp_dir = _frames_dir(output_path)
     submitted: List[int] = []
@@ -227,6 +231,8 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
     rendered = 0
     # the reference saves through a 2-thread PIL pool (render.py:4412-4413); here the frame is quantised
     # on the device, copied into a pinned ring and encoded by worker threads while the next frames render
+    if png_level == DEVICE and sink_workers <= 0:
+        sink_workers = 4                                 # copy + write only
     sink = FrameSink(renderer, slots=sink_slots, workers=sink_workers, level=png_level)
     if video_stream not in ("auto", "y4m", "off"):
         raise ValueError(f"video_stream must be 'auto', 'y4m' or 'off', got {video_stream!r}")
@@ -289,7 +295,7 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
         json.dump({"params": params, "completed": sorted(completed)}, f)
     if rendered:
         print(f"Session rendered {rendered} frames in {time.time() - total_t0:.1f} s "
-              f"({rendered / (time.time() - total_t0):.1f} fps incl. PNG encode, "
+              f"({rendered / (time.time() - total_t0):.1f} fps incl. PNG encode {'on the device' if png_level == DEVICE else f'(zlib level {png_level})'}, "
               f"{bytes_written / max(frames_written, 1) / 1e6:.2f} MB/frame, {sink.workers} encoder threads)")
     if world > 1 or not assemble:
         return       # rank 0 assembles after a barrier (cli.py)

@@ -19,6 +19,11 @@ from .lifecycle import FILAMENT_BIRTH_FADE_DUR, FILAMENT_DEATH_THRESHOLD, envelo
 
 FIL_DTYPE = np.dtype([("center", "<f8"), ("inv_2s_phi", "<f8"), ("coef_d", "<f8"), ("coef_t", "<f8")])
 ROL_DTYPE = np.dtype([("offset", "<i8"), ("shift", "<i4"), ("plane", "<i4"), ("alpha", "<f4"), ("stride", "<i4")])
+# bhr_filament_entity / bhr_rolled_entity (include/bhr_lifecycle.h): what bhr_accumulate_population consumes
+FIL_ENTITY = np.dtype([("birth_time", "<f8"), ("source_phi", "<f8"), ("sigma_phi0", "<f8"), ("shear_rate", "<f8"),
+                       ("peak_density", "<f8"), ("peak_temp", "<f8"), ("cooling_time", "<f8"), ("row_lo", "<i4"), ("n_rows", "<i4")])
+ROL_ENTITY = np.dtype([("birth_time", "<f8"), ("lifetime", "<f8"), ("ramp_in", "<f8"), ("ramp_out", "<f8"), ("offset", "<i8"),
+                       ("row_lo", "<i4"), ("n_rows", "<i4"), ("plane", "<i4"), ("pad_", "<i4")])
 _PLANE = {"rt_spike": 2, "hotspot": 4}
 _TWO_PI = 2 * np.pi
 
@@ -31,10 +36,11 @@ def _bind(lib):
     lib.bhr_entity_profile_upload.argtypes = [P, F, F, I32, C.POINTER(I64)]
     lib.bhr_entity_profile_reset.argtypes = [P]
     lib.bhr_accumulate_entities.argtypes = [P, P, C.POINTER(I32), P, C.POINTER(I32), D]
+    lib.bhr_accumulate_population.argtypes = [P, C.c_double, P, I32, D, P, I32, F]
     lib.bhr_stats_prepare.argtypes = [P, I32, C.POINTER(C.c_uint64)]
     lib.bhr_stats_select.argtypes = [P, I32, C.c_uint64, F]
     lib.bhr_stats_row_statistics.argtypes = [P, C.c_float, I32, I32, F]
-    for n in ("bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities",
+    for n in ("bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities", "bhr_accumulate_population",
               "bhr_stats_prepare", "bhr_stats_select", "bhr_stats_row_statistics"):
         getattr(lib, n).restype = I32
     lib._lifecycle_typed = True
@@ -174,6 +180,7 @@ class ProfilePool:
             _lib.check(self.lib.bhr_entity_profile_reset(self.ctx))
             self._live.clear()
             self._dead_since_reset = 0
+            self.generation = getattr(self, "generation", 0) + 1     # every offset handed out so far is void
 
 
 def accumulate_on_device(lib, ctx, pool: ProfilePool, factories: dict, now: float, n_r: int, n_phi: int,
@@ -192,6 +199,87 @@ def accumulate_on_device(lib, ctx, pool: ProfilePool, factories: dict, now: floa
         ctx, f_tab.ctypes.data_as(C.c_void_p) if len(f_tab) else None, i32p(f_ptr),
         r_tab.ctypes.data_as(C.c_void_p) if len(r_tab) else None, i32p(r_ptr),
         phi.ctypes.data_as(C.POINTER(C.c_double))))
+
+
+# --------------------------------------------------------------------------- entity records (the per-frame path)
+def _contiguous(rows: np.ndarray, n_r: int):
+    """(row_lo, n_rows) if the rows are a run lo, lo + 1, ... inside the texture, else None."""
+    if len(rows) == 0:
+        return 0, 0
+    lo, n = int(rows[0]), len(rows)
+    if lo < 0 or lo + n > n_r or int(rows[-1]) != lo + n - 1 or (n > 2 and not np.array_equal(rows, np.arange(lo, lo + n))):
+        return None
+    return lo, n
+
+
+class PopulationTables:
+    """Entity records for bhr_accumulate_population, rebuilt only when a population's member list changes (a birth
+    or a death; every fourth frame at the reference's rates).  The records hold what is static over an entity's life;
+    everything that depends on `now` is evaluated by the library."""
+
+    def __init__(self):
+        self._fil_key = self._rol_key = None
+        self.fil = np.zeros(0, dtype=FIL_ENTITY)
+        self.rw = np.zeros(0, dtype=np.float64)
+        self.rol = np.zeros(0, dtype=ROL_ENTITY)
+        self.usable = True
+
+    def filaments(self, factory, n_r, omega_rows, r_norm_all):
+        ents = factory.alive_entities if factory is not None else []
+        key = [id(e) for e in ents]
+        if key == self._fil_key:
+            return
+        recs, rws = [], []
+        for e in ents:
+            _, rows, r_w, _ = _filament_static(e, n_r, omega_rows, r_norm_all)
+            run = _contiguous(rows, n_r)
+            if run is None:
+                self.usable = False
+                return
+            recs.append((e.birth_time, e.source_phi, e.sigma_phi0, e.shear_rate, e.peak_density, e.peak_temp, e.cooling_time,
+                         run[0], run[1]))
+            rws.append(r_w)
+        self.fil = np.array(recs, dtype=FIL_ENTITY) if recs else np.zeros(0, dtype=FIL_ENTITY)
+        self.rw = np.ascontiguousarray(np.concatenate(rws)) if rws else np.zeros(0, dtype=np.float64)
+        self._fil_key = key
+        self._fil_refs = list(ents)          # ids stay unique while the objects are alive
+
+    def rolled(self, factories, n_r, n_phi, pool):
+        ents = [(k, e) for k in ("rt_spike", "hotspot") if factories.get(k) is not None for e in factories[k].alive_entities]
+        key = [getattr(pool, "generation", 0)] + [id(e) for _, e in ents]
+        if key == self._rol_key:
+            return
+        recs = []
+        for kind, e in ents:
+            off, _ = pool.offset_of(e)
+            run = _contiguous(np.asarray(e.row_indices), n_r)
+            if run is None:
+                self.usable = False
+                return
+            recs.append((e.birth_time, e.lifetime, e.ramp_in, e.ramp_out, off, run[0], run[1], _PLANE[kind], 0))
+        self.rol = np.array(recs, dtype=ROL_ENTITY) if recs else np.zeros(0, dtype=ROL_ENTITY)
+        self._rol_key = key
+        self._rol_refs = [e for _, e in ents]
+
+
+def accumulate_population(lib, ctx, pool: ProfilePool, tables: PopulationTables, factories: dict, now: float, n_r: int,
+                          n_phi: int, omega_rows: np.ndarray, r_norm_all: np.ndarray) -> bool:
+    """accumulate_entity_layer through bhr_accumulate_population; False if a population cannot be expressed as
+    entity records (rows that are not a contiguous run -- the caller falls back to accumulate_on_device)."""
+    _bind(lib)
+    pool.collect(factories)
+    if tables.usable:
+        tables.filaments(factories.get("filament"), n_r, omega_rows, r_norm_all)
+    if tables.usable:
+        tables.rolled(factories, n_r, n_phi, pool)
+    if not tables.usable:
+        return False
+    om = np.ascontiguousarray(omega_rows, dtype=np.float32)
+    _lib.check(lib.bhr_accumulate_population(
+        ctx, float(now), tables.fil.ctypes.data_as(C.c_void_p) if len(tables.fil) else None, len(tables.fil),
+        tables.rw.ctypes.data_as(C.POINTER(C.c_double)) if len(tables.rw) else None,
+        tables.rol.ctypes.data_as(C.c_void_p) if len(tables.rol) else None, len(tables.rol), _lib.fptr(om)))
+    return True
 
 
 # --------------------------------------------------------------------------- statistics

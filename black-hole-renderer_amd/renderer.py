@@ -277,12 +277,19 @@ class HipRenderer:
         _lib.check(self._lib.bhr_read_comp(self._ctx, _lib.fptr(out)))
         return out
 
-    def accumulate_entity_layer(self, factories: dict, now: float) -> None:
-        """Rasterise the alive entities into comp[5:11] on the device (render.py:3564-3653): the host sends
-        (entity, row) pair tables, csrc/lifecycle.hip does the per-texel work."""
+    def accumulate_entity_layer(self, factories: dict, now: float, pairs_on_host: bool = False) -> None:
+        """Rasterise the alive entities into comp[5:11] on the device (render.py:3564-3653).  The host hands over
+        entity records (rebuilt only when a population changes); the library evaluates the fades and the per-(entity,
+        row) scalars, csrc/lifecycle.hip does the per-texel work, nothing waits for the stream.
+        ``pairs_on_host=True`` builds the (entity, row) pair tables in NumPy instead (round-1 path, same result)."""
         from . import lifecycle_device as ld
         if getattr(self, "_profile_pool", None) is None:
             self._profile_pool = ld.ProfilePool(self._lib, self._ctx, self._bg_n_phi)
+            self._population_tables = ld.PopulationTables()
+        if not pairs_on_host and ld.accumulate_population(self._lib, self._ctx, self._profile_pool, self._population_tables,
+                                                          factories, now, self._bg_n_r, self._bg_n_phi,
+                                                          self._bg_omega_all_np, self._bg_r_norm_all):
+            return
         ld.accumulate_on_device(self._lib, self._ctx, self._profile_pool, factories, now, self._bg_n_r,
                                 self._bg_n_phi, self._bg_omega_all_np, self._bg_r_norm_all)
 

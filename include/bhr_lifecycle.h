@@ -51,6 +51,29 @@ BHR_API int32_t bhr_entity_profile_reset(bhr_ctx *ctx);
 BHR_API int32_t bhr_accumulate_entities(bhr_ctx *ctx, const bhr_filament_row *fil, const int32_t *fil_ptr,
                                         const bhr_rolled_row *rolled, const int32_t *rol_ptr, const double *phi);
 
+/* The same rasterisation from ENTITIES instead of pair tables: what the producer (lifecycle.EntityFactory, the
+ * reference's EntityFactory render.py:624-792) holds per structure, as Python floats.  The library evaluates
+ * filament_strength / the fade trapezoid and the per-(entity, row) scalars itself -- the reference's expressions with
+ * the reference's roundings (binary64 libm exp like math.exp; binary32 centre and roll arithmetic like NumPy's f32
+ * scalars, np.remainder semantics) -- groups the pairs by row and launches without waiting for the stream.
+ * Entities are visited in array order (filaments; then `rolled` in the order given: RT spikes before hotspots,
+ * render.py:3640-3649).  Rows of an entity are contiguous: [row_lo, row_lo + n_rows). */
+typedef struct {
+    double birth_time, source_phi, sigma_phi0, shear_rate, peak_density, peak_temp, cooling_time;
+    int32_t row_lo, n_rows;
+} bhr_filament_entity;
+typedef struct {
+    double birth_time, lifetime, ramp_in, ramp_out;   /* fade trapezoid: ramp in, plateau, ramp out */
+    int64_t offset;                                     /* bhr_entity_profile_upload's offset of its first density row */
+    int32_t row_lo, n_rows;
+    int32_t plane, pad_;                                /* 2 = RT spike, 4 = hotspot */
+} bhr_rolled_entity;
+/* radial_weights: for every filament in turn its n_rows binary64 radial weights exp(-(r_norm[row] - base_r)^2 / (2
+ * sigma_r^2)) (static over its life; computed by the producer).  omega_rows: (n_r) f32 Keplerian angular velocities. */
+BHR_API int32_t bhr_accumulate_population(bhr_ctx *ctx, double now, const bhr_filament_entity *filaments, int32_t n_filaments,
+                                          const double *radial_weights, const bhr_rolled_entity *rolled, int32_t n_rolled,
+                                          const float *omega_rows);
+
 /* recompute_interactive_stats on the device, in three steps so that the binding can apply NumPy's
  * own index and interpolation arithmetic (which depends on the NumPy version: 2.x evaluates the
  * virtual index (n - 1) q and the lerp in the array's dtype, f32):

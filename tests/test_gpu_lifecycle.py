@@ -60,6 +60,35 @@ def test_profile_pool_survives_turnover(hip_lib):
     r.close()
 
 
+@pytest.mark.parametrize("n_r,n_phi", [(48, 96), (416, 2912)])
+def test_entity_records_and_pair_tables_give_identical_layers(hip_lib, n_r, n_phi):
+    """bhr_accumulate_population (the library evaluates fades and per-row scalars from entity records) against
+    bhr_accumulate_entities fed with the NumPy-built pair tables: the same bits, through births, deaths, pool
+    rebuilds and frames without any change of population."""
+    from bhr_amd.lifecycle import make_factories
+    r = _renderer(n_r, n_phi)
+    r.init_background_layer(n_r, n_phi, seed=42)
+    fac = make_factories(n_r, n_phi, 2.0, 15.0, seed=42)
+    checked = 0
+    for k in range(0, 1201):
+        now = k * 0.1
+        if k:
+            for f in fac.values():
+                f.tick(now=now, dt=0.1)
+        if k % 150 == 0 or k in (1, 2, 3, 601, 602):
+            r.accumulate_entity_layer(fac, now)
+            got = r.read_comp()[5:11]
+            r.accumulate_entity_layer(fac, now, pairs_on_host=True)
+            want = r.read_comp()[5:11]
+            np.testing.assert_array_equal(got, want, err_msg=f"tick {k}")
+            assert want[0].max() > 0.05
+            checked += 1
+        elif k % 7 == 0:
+            r.accumulate_entity_layer(fac, now)            # keeps the record cache and the staging ring turning
+    assert checked >= 12 and r._population_tables.usable
+    r.close()
+
+
 def _use_host_lifecycle(r):
     """Checker configuration: the entity layer and the statistics from the reference-identical NumPy forms
     (tests/lifecycle_checker.py), uploaded through the C ABI -- what the device path is compared with."""

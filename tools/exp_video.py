@@ -1,5 +1,5 @@
 """Video driver throughput at fhd (configs[4]): frames/s end to end with the frame sink, and the
-time of each stage.  Usage: python tools/exp_video.py [n_frames] [png_level] [workers]"""
+time of each stage.  Usage: python tools/exp_video.py [n_frames] [png_level, -1 = device encoder] [workers]"""
 import os, sys, time, shutil, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -29,5 +29,12 @@ from bhr_amd.output import png_encode
 for lv, th in ((1, 1), (6, 1), (1, 8), (6, 8)):
     t0 = time.perf_counter(); d = png_encode(u8, lv, th); dt = time.perf_counter() - t0
     print(f"png_encode level {lv} threads {th}: {dt * 1e3:.1f} ms {len(d) / 1e6:.2f} MB")
+from bhr_amd.output import png_encode_device
+png_encode_device(r)
+t0 = time.perf_counter()
+for _ in range(20):
+    d = png_encode_device(r)
+dt = (time.perf_counter() - t0) / 20
+print(f"png_encode_device (quantise + 3 launches + fetch, synchronous): {dt * 1e3:.2f} ms {len(d) / 1e6:.2f} MB")
 r.close()
 shutil.rmtree(tmp)
