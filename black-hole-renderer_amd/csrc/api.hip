@@ -51,6 +51,7 @@ int32_t alloc_slot(bhr_ctx *ctx, int k) {
         else BHR_HIP(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
     }
     if (!f.done) BHR_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+    if (!f.march_done) BHR_HIP(hipEventCreateWithFlags(&f.march_done, hipEventDisableTiming));
     int32_t rc = BHR_OK;
     if ((rc = dev_alloc(&f.d_bg, px3)) || (rc = dev_alloc(&f.d_disk, px3)) || (rc = dev_alloc(&f.d_blur, px3)) ||
         (rc = dev_alloc(&f.d_final, px3)) || (rc = dev_alloc(&f.d_final_u8, px3)) ||
@@ -76,6 +77,7 @@ void free_slot(bhr_ctx *ctx, int k) {
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (f.done) (void)hipEventDestroy(f.done);
+    if (f.march_done) (void)hipEventDestroy(f.march_done);
     if (f.stream && f.stream != ctx->scene_stream) (void)hipStreamDestroy(f.stream);
     memset(&f, 0, sizeof(f));
 }
@@ -201,6 +203,42 @@ int32_t bhr_enter(bhr_ctx *ctx) {
         bhr_frame_slot &f = ctx->slots[k];
         if (f.in_flight && f.stream != ctx->scene_stream) BHR_HIP(hipStreamWaitEvent(ctx->scene_stream, f.done, 0));
         f.in_flight = 0;
+    }
+    ctx->stream = ctx->scene_stream;
+    return BHR_OK;
+}
+
+int32_t bhr_enter_components(bhr_ctx *ctx) {
+    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    ctx->stream = ctx->scene_stream;
+    return BHR_OK;
+}
+
+int32_t bhr_enter_scene_write(bhr_ctx *ctx) {
+    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    for (int k = 0; k < BHR_MAX_FRAME_SLOTS; ++k) {
+        bhr_frame_slot &f = ctx->slots[k];
+        if (f.in_flight && f.stream != ctx->scene_stream) BHR_HIP(hipStreamWaitEvent(ctx->scene_stream, f.march_done, 0));
+    }
+    ctx->stream = ctx->scene_stream;
+    return BHR_OK;
+}
+
+int32_t bhr_enter_frame(bhr_ctx *ctx) {
+    bhr_frame_slot &f = ctx->slots[ctx->active_slot];
+    if (!f.allocated || !f.stream || f.stream == ctx->scene_stream) return bhr_enter(ctx);
+    BHR_HIP(hipSetDevice(ctx->cfg.device));
+    BHR_HIP(hipEventRecord(ctx->scene_ev, ctx->scene_stream));      // e.g. a bhr_write_layer(FINAL) since the render
+    BHR_HIP(hipStreamWaitEvent(f.stream, ctx->scene_ev, 0));
+    ctx->stream = f.stream;
+    return BHR_OK;
+}
+
+int32_t bhr_leave_frame(bhr_ctx *ctx) {
+    bhr_frame_slot &f = ctx->slots[ctx->active_slot];
+    if (ctx->stream != ctx->scene_stream && ctx->stream == f.stream) {
+        BHR_HIP(hipEventRecord(f.done, f.stream));                  // joins now wait for this work too
+        f.in_flight = 1;
     }
     ctx->stream = ctx->scene_stream;
     return BHR_OK;
@@ -406,7 +444,7 @@ int32_t bhr_bg_init(bhr_ctx *ctx, int32_t n_r, int32_t n_phi, int32_t az_freq, f
 int32_t bhr_generate_background(bhr_ctx *ctx, float t) {
     if (!ctx) return bhr_fail(BHR_ERR_INVALID, "null ctx");
     if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call init_background_layer() first");
-    BHR_TRY(use_device(ctx));
+    BHR_TRY(bhr_enter_components(ctx));          // writes comp only: runs beside the frame in flight
     BHR_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     BHR_TRY(bhr_launch_background(ctx, t));
     BHR_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
@@ -457,7 +495,7 @@ int32_t bhr_set_compose_stats(bhr_ctx *ctx, float density_p98, float struct_scal
 int32_t bhr_compose_texture(bhr_ctx *ctx, float t_offset, int32_t enable_rt, float color_temp) {
     if (!ctx) return bhr_fail(BHR_ERR_INVALID, "null ctx");
     if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call upload_parametric_state() / init_background_layer() before composing");
-    BHR_TRY(use_device(ctx));
+    BHR_TRY(bhr_enter_scene_write(ctx));
     BHR_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
     BHR_TRY(bhr_launch_compose(ctx, t_offset, enable_rt, color_temp));
     BHR_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
@@ -493,6 +531,7 @@ int32_t render_on_slot(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags, int 
     bhr_frame_slot &f = ctx->slots[k];
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     BHR_TRY(bhr_launch_march(ctx, cam, flags));  // records the ring slot's march events
+    BHR_HIP(hipEventRecord(f.march_done, f.stream));
     if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctx));
     // the V kernel clears the counter cell BHR_MAX_FRAME_SLOTS frames ahead: no frame that may be in flight on another
     // slot's stream is counting into it (the next frames' marches may already be running)

@@ -86,7 +86,8 @@ struct bhr_frame_slot {
     float *d_bg, *d_disk, *d_hblur, *d_blur, *d_final;
     uint8_t *d_final_u8;
     unsigned int *d_queue;
-    hipEvent_t done;        // end of the slot's last bhr_render
+    hipEvent_t done;        // end of the slot's last bhr_render (and of frame work queued behind it: bhr_leave_frame)
+    hipEvent_t march_done;  // end of its march: the last reader of the scene (bhr_enter_scene_write)
     int32_t allocated;
     int32_t in_flight;      // rendered since the last join
 };
@@ -195,6 +196,18 @@ int32_t bhr_fail(int32_t code, const char *fmt, ...);
 // Every API entry point except bhr_render: selects the device and orders the scene stream behind the frames in
 // flight, so that scene writes, read-backs and stand-alone passes see (and never race with) a finished frame.
 int32_t bhr_enter(bhr_ctx *ctx);
+// Entry points that touch only the component planes / entity pool (comp, d_pool: read by no frame kernel) -- the
+// per-frame background and entity-layer passes -- select the scene stream WITHOUT joining the frames in flight, so that
+// the next frame's texture work runs beside the current march; bhr_compose_texture (full bhr_enter) is the join.
+int32_t bhr_enter_components(bhr_ctx *ctx);
+// Work that only reads the last rendered frame (quantise, PNG encode, copy out) rides the stream that rendered it:
+// bhr_enter_frame points ctx->stream at that slot's stream (ordered behind the scene stream), bhr_leave_frame
+// re-records the slot's completion event and restores the scene stream.  The scene stream stays free meanwhile.
+// bhr_compose_texture rewrites the disk texture and its mips, which only the MARCH of a frame in flight reads: the scene
+// stream waits for the marches, not for the bloom / flare / PNG work behind them.
+int32_t bhr_enter_scene_write(bhr_ctx *ctx);
+int32_t bhr_enter_frame(bhr_ctx *ctx);
+int32_t bhr_leave_frame(bhr_ctx *ctx);
 
 // launchers (each lives next to its kernels)
 int32_t bhr_launch_march(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);         // dispatches on math_mode

@@ -197,6 +197,8 @@ extern "C" {
 
 int32_t bhr_entity_profile_reset(bhr_ctx *ctx) {
     if (!ctx) return bhr_fail(BHR_ERR_INVALID, "null ctx");
+    BHR_TRY(bhr_enter_components(ctx));
+    BHR_HIP(hipStreamSynchronize(ctx->stream));     // an entity pass in flight may still read the profiles about to be overwritten
     ctx->pool_used = 0;
     return BHR_OK;
 }
@@ -205,7 +207,7 @@ int32_t bhr_entity_profile_upload(bhr_ctx *ctx, const float *density, const floa
                                   int64_t *offset_out) {
     if (!ctx || !density || !temp || n_rows <= 0 || !offset_out) return bhr_fail(BHR_ERR_INVALID, "bhr_entity_profile_upload: bad argument");
     if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call init_background_layer() first");
-    BHR_TRY(bhr_enter(ctx));
+    BHR_TRY(bhr_enter_components(ctx));
     const int64_t need = 2ll * n_rows * ctx->bg_n_phi;
     if (ctx->pool_used + need > ctx->pool_cap) {   // grow geometrically, keep the contents
         int64_t cap = ctx->pool_cap ? ctx->pool_cap : (int64_t)64 * ctx->bg_n_phi * 64;
@@ -220,10 +222,12 @@ int32_t bhr_entity_profile_upload(bhr_ctx *ctx, const float *density, const floa
         ctx->d_pool = p;
         ctx->pool_cap = cap;
     }
+    // Blocking copies into a region no launch has been given yet (the pool only grows between resets, and a reset waits
+    // for the stream): they need not queue behind the background pass on the scene stream, and the caller's arrays
+    // are free on return.
     const size_t half = (size_t)n_rows * ctx->bg_n_phi;
-    BHR_HIP(hipMemcpyAsync(ctx->d_pool + ctx->pool_used, density, half * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    BHR_HIP(hipMemcpyAsync(ctx->d_pool + ctx->pool_used + half, temp, half * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    BHR_HIP(hipStreamSynchronize(ctx->stream));
+    BHR_HIP(hipMemcpy(ctx->d_pool + ctx->pool_used, density, half * sizeof(float), hipMemcpyHostToDevice));
+    BHR_HIP(hipMemcpy(ctx->d_pool + ctx->pool_used + half, temp, half * sizeof(float), hipMemcpyHostToDevice));
     *offset_out = ctx->pool_used;
     ctx->pool_used += need;
     return BHR_OK;
@@ -233,7 +237,7 @@ int32_t bhr_accumulate_entities(bhr_ctx *ctx, const bhr_filament_row *fil, const
                                 const bhr_rolled_row *rolled, const int32_t *rol_ptr, const double *phi) {
     if (!ctx || !fil_ptr || !rol_ptr || !phi) return bhr_fail(BHR_ERR_INVALID, "bhr_accumulate_entities: bad argument");
     if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call init_background_layer() first");
-    BHR_TRY(bhr_enter(ctx));
+    BHR_TRY(bhr_enter_components(ctx));
     const int n_r = ctx->bg_n_r, n_phi = ctx->bg_n_phi;
     const int n_fil = fil_ptr[n_r], n_rol = rol_ptr[n_r];
     if ((n_fil > 0 && !fil) || (n_rol > 0 && !rolled)) return bhr_fail(BHR_ERR_INVALID, "bhr_accumulate_entities: missing pair table");
@@ -334,7 +338,7 @@ int32_t bhr_accumulate_population(bhr_ctx *ctx, double now, const bhr_filament_e
     if (!ctx || !omega_rows || n_fil < 0 || n_rolled < 0 || (n_fil > 0 && (!fil || !radial_weights)) || (n_rolled > 0 && !rolled))
         return bhr_fail(BHR_ERR_INVALID, "bhr_accumulate_population: bad argument");
     if (!ctx->bg_ready) return bhr_fail(BHR_ERR_STATE, "Must call init_background_layer() first");
-    BHR_TRY(bhr_enter(ctx));
+    BHR_TRY(bhr_enter_components(ctx));
     const int n_r = ctx->bg_n_r, n_phi = ctx->bg_n_phi;
     if (!ctx->pop_host) ctx->pop_host = new PopHost();
     PopHost *P = (PopHost *)ctx->pop_host;

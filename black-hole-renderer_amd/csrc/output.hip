@@ -523,7 +523,7 @@ int32_t bhr_sink_submit(bhr_sink *s, const char *path) {
     }
     bhr_ctx *ctx = s->ctx;
     hipError_t e = hipSuccess;
-    int32_t rc = bhr_enter(ctx);            // the scene stream follows the frame in flight; quantise + copy queue behind it
+    int32_t rc = bhr_enter_frame(ctx);      // quantise, encode and copy ride the stream that rendered the frame
     if (rc == BHR_OK) rc = bhr_launch_quantize(ctx);
     if (rc == BHR_OK && s->on_device) {
         bhr_sink::Slot &sl = s->slots[slot];
@@ -535,6 +535,10 @@ int32_t bhr_sink_submit(bhr_sink *s, const char *path) {
     } else if (rc == BHR_OK) {
         e = hipMemcpyAsync(s->slots[slot].host, ctx->d_final_u8, s->frame_bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(s->slots[slot].ev, ctx->stream);
+    }
+    {
+        const int32_t rc_leave = bhr_leave_frame(ctx);
+        if (rc == BHR_OK) rc = rc_leave;
     }
     if (e != hipSuccess || rc != BHR_OK) {
         std::lock_guard<std::mutex> lk(s->mu);

@@ -58,8 +58,9 @@ struct RowPlan {
 
 struct PngDev {
     PngTables *d_tab = nullptr;
-    RowPlan *d_plan = nullptr;
-    uint32_t *d_offs = nullptr;    // byte offset of every scanline's chunk
+    // scanline plans and chunk offsets, one set per frame slot: encodes of successive frames run on different streams
+    RowPlan *d_plan[BHR_MAX_FRAME_SLOTS] = {nullptr, nullptr};
+    uint32_t *d_offs[BHR_MAX_FRAME_SLOTS] = {nullptr, nullptr};
     uint32_t *d_meta = nullptr;    // [0] file length, [1] error (1: output buffer too small), [2] adler
     int32_t plan_rows = 0;
     int32_t head_w = 0, head_h = 0;
@@ -535,9 +536,13 @@ extern "C" int64_t bhr_png_device_bound(int32_t w, int32_t h) {
 void bhr_png_dev_free(bhr_ctx *ctx) {
     PngDev *d = dev_of(ctx);
     if (!d) return;
-    void *bufs[] = {d->d_tab, d->d_plan, d->d_offs, d->d_meta, d->d_out};
+    void *bufs[] = {d->d_tab, d->d_meta, d->d_out};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (int k = 0; k < BHR_MAX_FRAME_SLOTS; ++k) {
+        if (d->d_plan[k]) (void)hipFree(d->d_plan[k]);
+        if (d->d_offs[k]) (void)hipFree(d->d_offs[k]);
+    }
     delete d;
     ctx->png_dev = nullptr;
 }
@@ -561,13 +566,17 @@ int32_t bhr_png_dev_prepare(bhr_ctx *ctx) {
         d->head_h = h;
     }
     if (d->plan_rows < h) {
-        if (d->d_plan) (void)hipFree(d->d_plan);
-        if (d->d_offs) (void)hipFree(d->d_offs);
-        d->d_plan = nullptr;
-        d->d_offs = nullptr;
+        for (int k = 0; k < BHR_MAX_FRAME_SLOTS; ++k) {
+            if (d->d_plan[k]) (void)hipFree(d->d_plan[k]);
+            if (d->d_offs[k]) (void)hipFree(d->d_offs[k]);
+            d->d_plan[k] = nullptr;
+            d->d_offs[k] = nullptr;
+        }
         d->plan_rows = 0;
-        BHR_HIP(hipMalloc((void **)&d->d_plan, sizeof(RowPlan) * (size_t)h));
-        BHR_HIP(hipMalloc((void **)&d->d_offs, sizeof(uint32_t) * (size_t)h));
+        for (int k = 0; k < BHR_MAX_FRAME_SLOTS; ++k) {
+            BHR_HIP(hipMalloc((void **)&d->d_plan[k], sizeof(RowPlan) * (size_t)h));
+            BHR_HIP(hipMalloc((void **)&d->d_offs[k], sizeof(uint32_t) * (size_t)h));
+        }
         d->plan_rows = h;
     }
     if (!d->d_meta) BHR_HIP(hipMalloc((void **)&d->d_meta, 4 * sizeof(uint32_t)));
@@ -575,7 +584,7 @@ int32_t bhr_png_dev_prepare(bhr_ctx *ctx) {
 }
 
 // Encodes the (rows, W, 3) u8 image at d_rgb into d_out (cap bytes) on ctx->stream; d_meta_out (4 words, device)
-// receives {file length, error, adler, 0}.  The plan / offsets scratch is the context's: launches serialise on the stream.
+// receives {file length, error, adler, 0}.  The plan / offsets scratch is the active frame slot's.
 int32_t bhr_launch_png_encode(bhr_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_out, int64_t cap, uint32_t *d_meta_out) {
     BHR_TRY(bhr_png_dev_prepare(ctx));
     PngDev *d = dev_of(ctx);
@@ -591,10 +600,12 @@ int32_t bhr_launch_png_encode(bhr_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_out
         BHR_HIP(hipFuncSetAttribute((const void *)png_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         d->lds_attr = true;
     }
-    hipLaunchKernelGGL(png_plan_kernel, dim3(h), dim3(kThreads), lds_plan, ctx->stream, d_rgb, n, h, d->d_tab, d->d_plan);
-    hipLaunchKernelGGL(png_scan_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, d->d_plan, n, h, d->d_tab, d->d_offs, d_meta_out,
-                       d_out, (long long)cap);
-    hipLaunchKernelGGL(png_encode_kernel, dim3(h), dim3(kThreads), lds_enc, ctx->stream, d_rgb, n, h, d->d_tab, d->d_plan, d->d_offs,
+    RowPlan *plan = d->d_plan[ctx->active_slot];
+    uint32_t *offs = d->d_offs[ctx->active_slot];
+    hipLaunchKernelGGL(png_plan_kernel, dim3(h), dim3(kThreads), lds_plan, ctx->stream, d_rgb, n, h, d->d_tab, plan);
+    hipLaunchKernelGGL(png_scan_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, plan, n, h, d->d_tab, offs, d_meta_out, d_out,
+                       (long long)cap);
+    hipLaunchKernelGGL(png_encode_kernel, dim3(h), dim3(kThreads), lds_enc, ctx->stream, d_rgb, n, h, d->d_tab, plan, offs,
                        d_meta_out, d_out, cwords);
     BHR_HIP(hipGetLastError());
     return BHR_OK;

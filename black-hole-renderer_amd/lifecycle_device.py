@@ -231,33 +231,46 @@ class PopulationTables:
             return
         recs, rws = [], []
         for e in ents:
-            _, rows, r_w, _ = _filament_static(e, n_r, omega_rows, r_norm_all)
-            run = _contiguous(rows, n_r)
-            if run is None:
+            c = getattr(e, "_pop_record", None)
+            if c is None or c[0] != n_r:
+                _, rows, r_w, _ = _filament_static(e, n_r, omega_rows, r_norm_all)
+                run = _contiguous(rows, n_r)
+                rec = None if run is None else np.array(
+                    [(e.birth_time, e.source_phi, e.sigma_phi0, e.shear_rate, e.peak_density, e.peak_temp, e.cooling_time,
+                      run[0], run[1])], dtype=FIL_ENTITY).tobytes()
+                c = e._pop_record = (n_r, rec, np.ascontiguousarray(r_w, dtype=np.float64).tobytes())
+            if c[1] is None:
                 self.usable = False
                 return
-            recs.append((e.birth_time, e.source_phi, e.sigma_phi0, e.shear_rate, e.peak_density, e.peak_temp, e.cooling_time,
-                         run[0], run[1]))
-            rws.append(r_w)
-        self.fil = np.array(recs, dtype=FIL_ENTITY) if recs else np.zeros(0, dtype=FIL_ENTITY)
-        self.rw = np.ascontiguousarray(np.concatenate(rws)) if rws else np.zeros(0, dtype=np.float64)
+            recs.append(c[1])
+            rws.append(c[2])
+        # records are kept as bytes: joining 200 of them costs microseconds (np.concatenate of structured arrays: 0.4 ms)
+        self.fil = np.frombuffer(b"".join(recs), dtype=FIL_ENTITY)
+        self.rw = np.frombuffer(b"".join(rws), dtype=np.float64)
         self._fil_key = key
         self._fil_refs = list(ents)          # ids stay unique while the objects are alive
 
     def rolled(self, factories, n_r, n_phi, pool):
         ents = [(k, e) for k in ("rt_spike", "hotspot") if factories.get(k) is not None for e in factories[k].alive_entities]
-        key = [getattr(pool, "generation", 0)] + [id(e) for _, e in ents]
+        generation = getattr(pool, "generation", 0)
+        key = [id(pool), generation] + [id(e) for _, e in ents]
         if key == self._rol_key:
             return
         recs = []
         for kind, e in ents:
-            off, _ = pool.offset_of(e)
-            run = _contiguous(np.asarray(e.row_indices), n_r)
-            if run is None:
+            c = getattr(e, "_pop_record", None)
+            if c is None or c[0] != (n_r, n_phi, id(pool), generation):
+                off, _ = pool.offset_of(e)
+                run = _contiguous(np.asarray(e.row_indices), n_r)
+                rec = None if run is None else np.array(
+                    [(e.birth_time, e.lifetime, e.ramp_in, e.ramp_out, off, run[0], run[1], _PLANE[kind], 0)],
+                    dtype=ROL_ENTITY).tobytes()
+                c = e._pop_record = ((n_r, n_phi, id(pool), generation), rec)
+            if c[1] is None:
                 self.usable = False
                 return
-            recs.append((e.birth_time, e.lifetime, e.ramp_in, e.ramp_out, off, run[0], run[1], _PLANE[kind], 0))
-        self.rol = np.array(recs, dtype=ROL_ENTITY) if recs else np.zeros(0, dtype=ROL_ENTITY)
+            recs.append(c[1])
+        self.rol = np.frombuffer(b"".join(recs), dtype=ROL_ENTITY)
         self._rol_key = key
         self._rol_refs = [e for _, e in ents]
 
