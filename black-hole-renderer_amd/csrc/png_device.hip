@@ -36,16 +36,18 @@
 
 namespace {
 
-constexpr int kTables = 16;        // menu entries: 5 x 3 (q, b) codes + the flat code
+constexpr int kTables = 16;        // menu entries: 5 x 3 (q, b) codes + the flat code (16: one nibble each in len_nibbles)
 constexpr int kSyms = 257;         // literals 0..255 + end of block
 constexpr int kHdrWords = 64;      // room for a block header (<= 2048 bits)
 constexpr int kThreads = 256;
+constexpr int kScanThreads = 1024;
 constexpr uint32_t kPoly = 0xEDB88320u;
 
 struct PngTables {
     uint32_t code[kTables][260];   // (bit-reversed code << 4) | length, indexed by symbol
     uint32_t hdr[kTables][kHdrWords];
     uint32_t hdr_bits[kTables];
+    unsigned long long len_nibbles[260];   // code lengths of symbol s in all 16 menu entries, entry k at bits 4k..4k+3
     uint32_t crc_table[256];
     uint32_t x2n[32];              // x^(2^k) mod P, reflected (zlib's x2n_table)
     uint8_t head[40];              // signature + IHDR chunk (33 bytes)
@@ -206,7 +208,10 @@ bool fill_tables(PngTables *t) {
         }
         const std::vector<int> len = huffman_lengths(freq, 15);
         const std::vector<uint32_t> code = canonical_reversed(len);
-        for (int s = 0; s < kSyms; ++s) t->code[k][s] = (code[s] << 4) | (uint32_t)len[s];
+        for (int s = 0; s < kSyms; ++s) {
+            t->code[k][s] = (code[s] << 4) | (uint32_t)len[s];
+            t->len_nibbles[s] |= (unsigned long long)len[s] << (4 * k);
+        }
         const BitString h = block_header(len);
         if (h.words.size() > (size_t)kHdrWords) return false;
         t->hdr_bits[k] = h.bits;
@@ -244,10 +249,63 @@ __device__ __forceinline__ int paeth_pred(int a, int b, int c) {
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-// filtered byte i of the scanline in LDS (cur, up; up = zeros above the first row), filter type f
-__device__ __forceinline__ uint32_t filtered(int f, const uint8_t *cur, const uint8_t *up, int i) {
-    const int x = cur[i], b = up[i];
-    const int a = i >= 3 ? cur[i - 3] : 0, c = i >= 3 ? up[i - 3] : 0;
+// Scanline buffers in LDS: 16 zero bytes, the n bytes of the row, zeros up to a multiple of 16.  The zero prefix
+// stands for the pixel left of the first one (PNG: "bytes to the left of the first pixel are zero"), so no position needs
+// a branch; rows are processed four bytes (one aligned LDS word per operand) at a time.
+constexpr int kRowPrefix = 16;
+__device__ __forceinline__ int row_stride(int n) { return kRowPrefix + ((n + 15) & ~15); }
+
+// The scanline and the one above it -> LDS (cur, up point behind the prefix).  16-byte loads when the rows are 16-byte
+// aligned (every width that is a multiple of 16: all BASELINE sizes); otherwise bytes, eight loads in flight per thread.
+__device__ __forceinline__ void load_rows(const uint8_t *__restrict__ rgb, int row, int n, uint8_t *cur, uint8_t *up) {
+    const uint8_t *g = rgb + (size_t)row * n;
+    const int npad = (n + 15) & ~15;
+    if (threadIdx.x < 4) {
+        ((uint32_t *)(cur - kRowPrefix))[threadIdx.x] = 0u;
+        ((uint32_t *)(up - kRowPrefix))[threadIdx.x] = 0u;
+    }
+    if ((n & 15) == 0 && (((uintptr_t)rgb) & 15) == 0) {
+        const uint4 *g4 = (const uint4 *)g, *u4 = (const uint4 *)(g - n);
+        uint4 *c4 = (uint4 *)cur, *p4 = (uint4 *)up;
+        for (int v = threadIdx.x; v < (n >> 4); v += kThreads) {
+            c4[v] = g4[v];
+            p4[v] = row > 0 ? u4[v] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        return;
+    }
+    for (int i0 = 0; i0 < npad; i0 += 8 * kThreads) {
+        uint8_t a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * kThreads + (int)threadIdx.x;
+            a[k] = i < n ? g[i] : (uint8_t)0;
+            b[k] = (i < n && row > 0) ? g[i - n] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * kThreads + (int)threadIdx.x;
+            if (i < npad) { cur[i] = a[k]; up[i] = b[k]; }          // the tail up to npad is zero
+        }
+    }
+}
+
+// Operands of bytes i .. i + 3 (i a multiple of 4): x = the bytes, a = three to the left, b = above, c = above-left.
+struct Quad { uint32_t x, a, b, c; };
+__device__ __forceinline__ Quad load_quad(const uint8_t *cur, const uint8_t *up, int i) {
+    const uint32_t x = *(const uint32_t *)(cur + i), xp = *(const uint32_t *)(cur + i - 4);
+    const uint32_t b = *(const uint32_t *)(up + i), bp = *(const uint32_t *)(up + i - 4);
+    Quad q;
+    q.x = x;
+    q.b = b;
+    q.a = __byte_perm(xp, x, 0x4321);      // bytes i-3, i-2, i-1, i
+    q.c = __byte_perm(bp, b, 0x4321);
+    return q;
+}
+
+// residual of byte k of the quad under filter f (0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth), 0..255
+__device__ __forceinline__ uint32_t residual(int f, const Quad &q, int k) {
+    const int x = (int)((q.x >> (8 * k)) & 255u), a = (int)((q.a >> (8 * k)) & 255u);
+    const int b = (int)((q.b >> (8 * k)) & 255u), c = (int)((q.c >> (8 * k)) & 255u);
     int pred;
     switch (f) {
         case 0: pred = 0; break;
@@ -259,12 +317,15 @@ __device__ __forceinline__ uint32_t filtered(int f, const uint8_t *cur, const ui
     return (uint32_t)(x - pred) & 255u;
 }
 
-__device__ __forceinline__ void load_rows(const uint8_t *__restrict__ rgb, int row, int n, uint8_t *cur, uint8_t *up) {
-    const uint8_t *g = rgb + (size_t)row * n;
-    for (int i = threadIdx.x; i < n; i += kThreads) {
-        cur[i] = g[i];
-        up[i] = row > 0 ? g[i - n] : (uint8_t)0;
-    }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
 }
 
 // K1: per scanline -- filter choice, histogram, code choice, size, Adler partial sums.
@@ -275,26 +336,33 @@ __global__ __launch_bounds__(kThreads) void png_plan_kernel(const uint8_t *__res
     __shared__ uint32_t cost[5];
     __shared__ uint32_t bits[kTables];
     __shared__ unsigned long long ab[2];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    uint8_t *cur = smem, *up = smem + ((n + 15) & ~15);
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    uint8_t *cur = smem + kRowPrefix, *up = cur + row_stride(n);
     for (int i = tid; i < kSyms + 3; i += kThreads) hist[i] = 0;
     if (tid < 5) cost[tid] = 0;
     if (tid < kTables) bits[tid] = 0;
     if (tid < 2) ab[tid] = 0;
     load_rows(rgb, row, n, cur, up);
     __syncthreads();
-    const int per = (n + kThreads - 1) / kThreads, i0 = tid * per, i1 = min(i0 + per, n);
-    {
+    {   // sum of |signed residual| for the five filters; neighbouring lanes read neighbouring words
         uint32_t c[5] = {0, 0, 0, 0, 0};
-        for (int i = i0; i < i1; ++i)
+#pragma unroll 2
+        for (int i = 4 * tid; i < n; i += 4 * kThreads) {
+            const Quad q = load_quad(cur, up, i);
 #pragma unroll
-            for (int f = 0; f < 5; ++f) {
-                const int v = (int)(int8_t)filtered(f, cur, up, i);
-                c[f] += (uint32_t)(v < 0 ? -v : v);
-            }
+            for (int k = 0; k < 4; ++k)
+                if (i + k < n)
 #pragma unroll
-        for (int f = 0; f < 5; ++f)
-            if (c[f]) atomicAdd(&cost[f], c[f]);
+                    for (int f = 0; f < 5; ++f) {
+                        const uint32_t d = residual(f, q, k);
+                        c[f] += min(d, 256u - d);
+                    }
+        }
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const uint32_t t = wave_sum(c[f]);
+            if (lane == 0) atomicAdd(&cost[f], t);
+        }
     }
     __syncthreads();
     int best = 0;
@@ -303,69 +371,90 @@ __global__ __launch_bounds__(kThreads) void png_plan_kernel(const uint8_t *__res
         if (cost[f] < cost[best]) best = f;
     {
         const unsigned long long N = (unsigned long long)n + 1;        // filter byte + n residuals
-        unsigned long long a = 0, b = 0;
-        for (int i = i0; i < i1; ++i) {
-            const uint32_t d = filtered(best, cur, up, i);
-            atomicAdd(&hist[d], 1u);
-            a += d;
-            b += (N - 1 - (unsigned long long)i) * d;                  // stream position of residual i is i + 1
+        uint32_t a = 0, zeros = 0;                                     // most residuals are zero: counted in a register
+        unsigned long long b = 0;
+#pragma unroll 2
+        for (int i = 4 * tid; i < n; i += 4 * kThreads) {
+            const Quad q = load_quad(cur, up, i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + k < n) {
+                    const uint32_t d = residual(best, q, k);
+                    if (d) atomicAdd(&hist[d], 1u); else ++zeros;
+                    a += d;
+                    b += (unsigned long long)((uint32_t)n - (uint32_t)(i + k)) * d;   // stream position of residual i is i + 1
+                }
+        }
+        const uint32_t z = wave_sum(zeros), ta = wave_sum(a);
+        const unsigned long long tb = wave_sum64(b);
+        if (lane == 0) {
+            if (z) atomicAdd(&hist[0], z);
+            atomicAdd(&ab[0], (unsigned long long)ta);
+            atomicAdd(&ab[1], tb);
         }
         if (tid == 0) {
             atomicAdd(&hist[best], 1u);
-            a += (unsigned long long)best;
-            b += N * (unsigned long long)best;
-            hist[256] = 1;
+            atomicAdd(&ab[0], (unsigned long long)best);
+            atomicAdd(&ab[1], N * (unsigned long long)best);
         }
-        atomicAdd(&ab[0], a);
-        atomicAdd(&ab[1], b);
     }
     __syncthreads();
-    for (int s = tid; s < kSyms; s += kThreads) {
-        const uint32_t cnt = hist[s];
-        if (cnt)
+    {   // bits of the scanline under each menu entry: histogram x code lengths (16 nibbles per symbol)
+        const uint32_t cnt = hist[tid];                                // kThreads == 256 literals
+        const unsigned long long nib = tab->len_nibbles[tid];
 #pragma unroll
-            for (int k = 0; k < kTables; ++k) atomicAdd(&bits[k], cnt * (tab->code[k][s] & 15u));
+        for (int k = 0; k < kTables; ++k) {
+            const uint32_t t = wave_sum(cnt * (uint32_t)((nib >> (4 * k)) & 15ull));
+            if (lane == 0) atomicAdd(&bits[k], t);
+        }
     }
     __syncthreads();
-    if (tid == 0) {
-        int kb = 0;
-        uint32_t best_bits = bits[0] + tab->hdr_bits[0];
-        for (int k = 1; k < kTables; ++k) {
-            const uint32_t t = bits[k] + tab->hdr_bits[k];
-            if (t < best_bits) { best_bits = t; kb = k; }
+    if (tid < kTables) {
+        // + end of block + block header; then the smallest total, the lowest entry on ties
+        const uint32_t total = bits[tid] + (uint32_t)((tab->len_nibbles[256] >> (4 * tid)) & 15ull) + tab->hdr_bits[tid];
+        uint32_t best_bits = total;
+        int kb = tid;
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) {
+            const uint32_t ob = __shfl_xor(best_bits, d, 64);
+            const int ok = __shfl_xor(kb, d, 64);
+            if (ob < best_bits || (ob == best_bits && ok < kb)) { best_bits = ob; kb = ok; }
         }
-        // header + symbols + end of block, then the stored block: 3 bits, padding, LEN, NLEN
-        uint32_t payload = (best_bits + 3 + 7) / 8 + 4;
-        if (row == 0) payload += 2;                                    // zlib header
-        if (row == h - 1) payload += 4;                                // Adler-32
-        RowPlan p;
-        p.filter = (uint32_t)best;
-        p.table = (uint32_t)kb;
-        p.chunk_bytes = payload + 12;
-        p.data_bits = bits[kb];
-        p.a = ab[0];
-        p.b = ab[1];
-        plan[row] = p;
+        if (tid == 0) {
+            // header + symbols + end of block, then the stored block: 3 bits, padding, LEN, NLEN
+            uint32_t payload = (best_bits + 3 + 7) / 8 + 4;
+            if (row == 0) payload += 2;                                // zlib header
+            if (row == h - 1) payload += 4;                            // Adler-32
+            RowPlan p;
+            p.filter = (uint32_t)best;
+            p.table = (uint32_t)kb;
+            p.chunk_bytes = payload + 12;
+            p.data_bits = best_bits - tab->hdr_bits[kb];
+            p.a = ab[0];
+            p.b = ab[1];
+            plan[row] = p;
+        }
     }
 }
 
 // K2: chunk offsets (exclusive scan), Adler-32 of the whole filtered stream, file head and tail.
-__global__ __launch_bounds__(kThreads) void png_scan_kernel(const RowPlan *__restrict__ plan, int n, int h,
+__global__ __launch_bounds__(kScanThreads) void png_scan_kernel(const RowPlan *__restrict__ plan, int n, int h,
                                                             const PngTables *__restrict__ tab, uint32_t *__restrict__ offs,
                                                             uint32_t *__restrict__ meta, uint8_t *__restrict__ out, long long cap) {
-    __shared__ unsigned long long sc[kThreads], sa[kThreads];
+    __shared__ unsigned long long sc[kScanThreads], sa[kScanThreads];
     __shared__ unsigned long long carry_off, carry_a, s2_acc;
     const int tid = threadIdx.x;
     if (tid == 0) { carry_off = 33; carry_a = 1; s2_acc = 0; }       // after signature + IHDR; Adler s1 starts at 1
     __syncthreads();
     const unsigned long long N = (unsigned long long)n + 1, M = 65521ull;
-    for (int base = 0; base < h; base += kThreads) {
+    unsigned long long s2_mine = 0;
+    for (int base = 0; base < h; base += kScanThreads) {
         const int r = base + tid;
         const unsigned long long len = r < h ? plan[r].chunk_bytes : 0ull, a = r < h ? plan[r].a : 0ull;
         sc[tid] = len;
         sa[tid] = a;
         __syncthreads();
-        for (int d = 1; d < kThreads; d <<= 1) {                      // inclusive scans
+        for (int d = 1; d < kScanThreads; d <<= 1) {                      // inclusive scans
             const unsigned long long vc = tid >= d ? sc[tid - d] : 0ull, va = tid >= d ? sa[tid - d] : 0ull;
             __syncthreads();
             sc[tid] += vc;
@@ -375,22 +464,31 @@ __global__ __launch_bounds__(kThreads) void png_scan_kernel(const RowPlan *__res
         if (r < h) {
             offs[r] = (uint32_t)(carry_off + sc[tid] - len);
             const unsigned long long s1_before = (carry_a + sa[tid] - a) % M;
-            atomicAdd(&s2_acc, (N % M * s1_before + plan[r].b % M) % M);
+            s2_mine += (N % M * s1_before + plan[r].b % M) % M;
         }
         __syncthreads();
-        if (tid == 0) { carry_off += sc[kThreads - 1]; carry_a += sa[kThreads - 1]; }
+        if (tid == 0) { carry_off += sc[kScanThreads - 1]; carry_a += sa[kScanThreads - 1]; }
         __syncthreads();
     }
+    {
+        const unsigned long long t = wave_sum64(s2_mine);
+        if ((tid & 63) == 0) atomicAdd(&s2_acc, t);
+    }
+    __syncthreads();
+    const unsigned long long total = carry_off + 12;                  // + IEND
+    const bool too_big = total > (unsigned long long)cap || total > 0xFFFFFFF0ull;
     if (tid == 0) {
-        const unsigned long long total = carry_off + 12;              // + IEND
-        const uint32_t adler = (uint32_t)(((s2_acc % M) << 16) | (carry_a % M));
         meta[0] = (uint32_t)total;
-        meta[1] = (total > (unsigned long long)cap || total > 0xFFFFFFF0ull) ? 1u : 0u;
-        meta[2] = adler;
-        if (!meta[1]) {
-            for (int i = 0; i < 33; ++i) out[i] = tab->head[i];
-            static const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
-            for (int i = 0; i < 12; ++i) out[carry_off + i] = iend[i];
+        meta[1] = too_big ? 1u : 0u;
+        meta[2] = (uint32_t)(((s2_acc % M) << 16) | (carry_a % M));
+    }
+    if (!too_big) {
+        const uint32_t iend_lo = 0x00000000u, iend_mid = 0x444E4549u, iend_hi = 0x826042AEu;   // 0 | "IEND" | CRC, as stored
+        if (tid < 33) out[tid] = tab->head[tid];
+        else if (tid < 45) {
+            const int k = tid - 33;
+            const uint32_t w = k < 4 ? iend_lo : (k < 8 ? iend_mid : iend_hi);
+            out[carry_off + k] = (uint8_t)(w >> (8 * (k & 3)));
         }
     }
 }
@@ -417,25 +515,38 @@ __global__ __launch_bounds__(kThreads) void png_encode_kernel(const uint8_t *__r
     __shared__ uint32_t crc_acc;
     if (meta[1]) return;                                               // the plan does not fit the output buffer
     const int row = blockIdx.x, tid = threadIdx.x;
-    const int npad = (n + 15) & ~15;
-    uint8_t *cur = smem, *up = smem + npad, *fb = smem + 2 * npad;     // fb: filter byte + residuals (n + 1)
-    uint32_t *cw = (uint32_t *)(smem + 2 * npad + ((n + 1 + 15) & ~15));   // the chunk, word addressed
+    // LDS: [the two rows | later: the chunk being assembled] [fb: filter byte + residuals (n + 1)].  The chunk reuses the
+    // rows' space once they have been filtered (8k: 69 KB per block instead of 95, two blocks per CU).
+    const int rows_bytes = max(2 * row_stride(n), 4 * chunk_words);
+    uint8_t *cur = smem + kRowPrefix, *up = cur + row_stride(n), *fb = smem + ((rows_bytes + 15) & ~15);
+    uint32_t *cw = (uint32_t *)smem;                                   // the chunk, word addressed
     uint8_t *cb = (uint8_t *)cw;
     const RowPlan p = plan[row];
     for (int i = tid; i < kSyms; i += kThreads) codes[i] = tab->code[p.table][i];
     crc_tab[tid] = tab->crc_table[tid];
-    for (int i = tid; i < chunk_words; i += kThreads) cw[i] = 0;
     if (tid == 0) crc_acc = 0;
     load_rows(rgb, row, n, cur, up);
     __syncthreads();
-    for (int i = tid; i < n; i += kThreads) fb[i + 1] = (uint8_t)filtered((int)p.filter, cur, up, i);
+    for (int i = 4 * tid; i < n; i += 4 * kThreads) {
+        const Quad q = load_quad(cur, up, i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k < n) fb[i + 1 + k] = (uint8_t)residual((int)p.filter, q, k);
+    }
     if (tid == 0) fb[0] = (uint8_t)p.filter;
     __syncthreads();
 
+    for (int i = tid; i < chunk_words; i += kThreads) cw[i] = 0;       // the rows are dead: their space becomes the chunk
     const int N = n + 1;
-    const int per = (N + kThreads - 1) / kThreads, i0 = min(tid * per, N), i1 = min(i0 + per, N);
+    // contiguous slices of whole words of fb: four symbols per LDS read, four independent code lookups
+    const int per = (((N + kThreads - 1) / kThreads) + 3) & ~3, i0 = min(tid * per, N), i1 = min(i0 + per, N);
     uint32_t my_bits = 0;
-    for (int i = i0; i < i1; ++i) my_bits += codes[fb[i]] & 15u;
+    for (int i = i0; i < i1; i += 4) {
+        const uint32_t w = *(const uint32_t *)(fb + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k < i1) my_bits += codes[(w >> (8 * k)) & 255u] & 15u;
+    }
     scan[tid] = my_bits;
     __syncthreads();
     for (int d = 1; d < kThreads; d <<= 1) {
@@ -457,16 +568,23 @@ __global__ __launch_bounds__(kThreads) void png_encode_kernel(const uint8_t *__r
     {   // the symbols of this thread's slice
         uint32_t pos = data0 + scan[tid] - my_bits, wi = pos >> 5, nb = pos & 31u;
         unsigned long long acc = 0;
-        for (int i = i0; i < i1; ++i) {
-            const uint32_t c = codes[fb[i]];
-            acc |= (unsigned long long)(c >> 4) << nb;
-            nb += c & 15u;
-            if (nb >= 32u) {
-                atomicOr(&cw[wi], (uint32_t)acc);
-                acc >>= 32;
-                nb -= 32u;
-                ++wi;
-            }
+        for (int i = i0; i < i1; i += 4) {
+            const uint32_t w = *(const uint32_t *)(fb + i);
+            uint32_t c4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c4[k] = codes[(w >> (8 * k)) & 255u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + k < i1) {
+                    acc |= (unsigned long long)(c4[k] >> 4) << nb;
+                    nb += c4[k] & 15u;
+                    if (nb >= 32u) {
+                        atomicOr(&cw[wi], (uint32_t)acc);
+                        acc >>= 32;
+                        nb -= 32u;
+                        ++wi;
+                    }
+                }
         }
         if (nb && acc) atomicOr(&cw[wi], (uint32_t)acc);
     }
@@ -591,8 +709,9 @@ int32_t bhr_launch_png_encode(bhr_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_out
     const int n = 3 * ctx->cfg.width, h = ctx->rows;
     const int npad = (n + 15) & ~15;
     const int cwords = chunk_words_for(n);
-    const size_t lds_plan = (size_t)2 * npad;
-    const size_t lds_enc = (size_t)2 * npad + ((n + 1 + 15) & ~15) + (size_t)4 * cwords;
+    const size_t row_buf = 16 + (size_t)npad;                       // kRowPrefix + padded row (row_stride)
+    const size_t lds_plan = 2 * row_buf;
+    const size_t lds_enc = ((std::max(2 * row_buf, (size_t)4 * cwords) + 15) & ~(size_t)15) + ((n + 1 + 15) & ~15);
     if (lds_enc > 150 * 1024)
         return bhr_fail(BHR_ERR_INVALID, "device PNG encoder: a scanline of %d bytes does not fit LDS (%zu bytes needed)", n, lds_enc);
     if (!d->lds_attr) {
@@ -603,7 +722,7 @@ int32_t bhr_launch_png_encode(bhr_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_out
     RowPlan *plan = d->d_plan[ctx->active_slot];
     uint32_t *offs = d->d_offs[ctx->active_slot];
     hipLaunchKernelGGL(png_plan_kernel, dim3(h), dim3(kThreads), lds_plan, ctx->stream, d_rgb, n, h, d->d_tab, plan);
-    hipLaunchKernelGGL(png_scan_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, plan, n, h, d->d_tab, offs, d_meta_out, d_out,
+    hipLaunchKernelGGL(png_scan_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, plan, n, h, d->d_tab, offs, d_meta_out, d_out,
                        (long long)cap);
     hipLaunchKernelGGL(png_encode_kernel, dim3(h), dim3(kThreads), lds_enc, ctx->stream, d_rgb, n, h, d->d_tab, plan, offs,
                        d_meta_out, d_out, cwords);
