@@ -8,7 +8,7 @@ OUT=/tmp/bhr_asan
 mkdir -p $OUT
 cd $ROOT/black-hole-renderer_amd/csrc
 make -s
-for f in api output flare lifecycle api_disk_v2 disk_v2 bloom texture skyglow; do
+for f in api output png_device flare lifecycle api_disk_v2 disk_v2 bloom texture skyglow; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -DBHR_BUILD -fsanitize=address \
       -fno-omit-frame-pointer -Wno-option-ignored -c $f.hip -o $OUT/$f.o &
 done
@@ -17,4 +17,4 @@ cp ../lib/obj/march.o ../lib/obj/march_strict.o ../lib/obj/march_strict_ilp.o $O
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -o $OUT/libbhr_hip.so $OUT/*.o -lz -lpthread
 ASAN=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 cd $ROOT
-ASAN_OPTIONS=detect_leaks=0 BHR_HIP_LIBRARY=$OUT/libbhr_hip.so LD_PRELOAD=$ASAN python -m pytest tests/test_png.py tests/test_abi.py -q
+ASAN_OPTIONS=detect_leaks=0 BHR_HIP_LIBRARY=$OUT/libbhr_hip.so LD_PRELOAD=$ASAN python -m pytest tests/test_png.py tests/test_abi.py tests/test_png_device.py -q -m "not gpu"
