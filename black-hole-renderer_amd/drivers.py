@@ -82,7 +82,7 @@ def use_analytic_disk(renderer: HipRenderer, disk_model: str) -> bool:
 def make_renderer(width, height, cam_pos, fov, step_size=0.1, skybox_path=None, n_stars=6000, tex_w=2048,
                   tex_h=1024, r_max=10.0, disk_texture_path=None, r_disk_inner=R_DISK_INNER_DEFAULT,
                   r_disk_outer=R_DISK_OUTER_DEFAULT, disk_tilt=0.0, lens_flare=False, anti_alias="disabled",
-                  aa_strength=1.0, disk_rotation_speed=0.1, device_index=0, rows=None):
+                  aa_strength=1.0, disk_rotation_speed=0.1, device_index=0, rows=None, frame_slots=None):
     """Renderer with a placeholder (or file) disk texture, as the reference's entry points build it
     (render.py:4044-4064, 4627-4644).  Returns (renderer, use_lifecycle, n_r, n_phi)."""
     # procedural sky: the host draws its random tables, the device rasterises them (nebula resize, star blobs in
@@ -104,7 +104,8 @@ def make_renderer(width, height, cam_pos, fov, step_size=0.1, skybox_path=None, 
     renderer = HipRenderer(width, height, skybox, disk_tex, step_size=step_size, r_max=r_max,
                            r_disk_inner=r_disk_inner, r_disk_outer=r_disk_outer, disk_tilt=disk_tilt,
                            lens_flare=lens_flare, anti_alias=anti_alias, aa_strength=aa_strength,
-                           disk_rotation_speed=disk_rotation_speed, device_index=device_index, rows=rows)
+                           disk_rotation_speed=disk_rotation_speed, device_index=device_index, rows=rows,
+                           frame_slots=frame_slots)
     if procedural_sky:
         renderer.build_procedural_skybox(seed=42, n_stars=n_stars)
     return renderer, use_lifecycle, n_r, n_phi
