@@ -35,14 +35,20 @@ __constant__ int c_perm256[256] = {
 };
 
 // perm_field = _perm + _perm (512 entries, render.py:2287-2288) staged in LDS.
-__device__ __forceinline__ void load_perm(int *perm) {
-    for (int k = threadIdx.x; k < 512; k += blockDim.x) perm[k] = c_perm256[k & 255];
+// perm[0..511] = the table, perm[512..1023] = the table modulo 12: the gradient index h = hash % 12 of the four corner
+// hashes is read directly instead of being computed (four integer divisions by a constant per evaluation).
+typedef uint8_t perm_t;   // byte tables: 1 KB in all, lanes that hit the same LDS word are served by one broadcast
+__device__ __forceinline__ void load_perm(perm_t *perm) {
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) {
+        const int v = c_perm256[k & 255];
+        perm[k] = (perm_t)v;
+        perm[512 + k] = (perm_t)(v % 12);
+    }
     __syncthreads();
 }
 
 // _grad3_dot (render.py:2642-2660): h = hash % 12 so the "h == 12 or 14" arm is dead.
-__device__ __forceinline__ float grad3_dot(int hash_val, float x, float y, float z) {
-    int h = hash_val % 12;  // hash_val >= 0
+__device__ __forceinline__ float grad3_dot(int h, float x, float y, float z) {   // h = hash % 12 (load_perm)
     float u = h < 8 ? x : y;
     float v = h < 4 ? y : z;
     float r1 = (h & 1) == 0 ? u : -u;
@@ -51,7 +57,7 @@ __device__ __forceinline__ float grad3_dot(int hash_val, float x, float y, float
 }
 
 // _simplex_noise_3d (render.py:2662-2750)
-__device__ __forceinline__ float simplex3(const int *perm, float x, float y, float z) {
+__device__ __forceinline__ float simplex3(const perm_t *perm, float x, float y, float z) {
     const float F3 = 1.0f / 3.0f;
     const float G3 = 1.0f / 6.0f;
     float s = (x + y + z) * F3;
@@ -77,10 +83,11 @@ __device__ __forceinline__ float simplex3(const int *perm, float x, float y, flo
     float x3 = x0 - 1.0f + 3.0f * G3, y3 = y0 - 1.0f + 3.0f * G3, z3 = z0 - 1.0f + 3.0f * G3;
     int ii = i & 255, jj = j & 255, kk = k & 255;
     int pk0 = perm[kk], pk1 = perm[kk + 1];
-    int gi0 = perm[ii + perm[jj + pk0]];
-    int gi1 = perm[ii + i1 + perm[jj + j1 + (k1 ? pk1 : pk0)]];
-    int gi2 = perm[ii + i2 + perm[jj + j2 + (k2 ? pk1 : pk0)]];
-    int gi3 = perm[ii + 1 + perm[jj + 1 + pk1]];
+    const perm_t *perm12 = perm + 512;
+    int gi0 = perm12[ii + perm[jj + pk0]];
+    int gi1 = perm12[ii + i1 + perm[jj + j1 + (k1 ? pk1 : pk0)]];
+    int gi2 = perm12[ii + i2 + perm[jj + j2 + (k2 ? pk1 : pk0)]];
+    int gi3 = perm12[ii + 1 + perm[jj + 1 + pk1]];
     float n = 0.0f;
     float t0 = 0.6f - x0 * x0 - y0 * y0 - z0 * z0;
     if (t0 >= 0.0f) { t0 = t0 * t0; n += t0 * t0 * grad3_dot(gi0, x0, y0, z0); }
@@ -95,7 +102,7 @@ __device__ __forceinline__ float simplex3(const int *perm, float x, float y, flo
 
 // _fbm_3d (render.py:2752-2785)
 template <int OCT>
-__device__ __forceinline__ float fbm3(const int *perm, float x, float y, float z, float persistence,
+__device__ __forceinline__ float fbm3(const perm_t *perm, float x, float y, float z, float persistence,
                                       float lacunarity) {
     float value = 0.0f, amplitude = 1.0f, freq = 1.0f;
 #pragma unroll
@@ -106,7 +113,7 @@ __device__ __forceinline__ float fbm3(const int *perm, float x, float y, float z
     }
     return value;
 }
-__device__ float fbm3_dyn(const int *perm, float x, float y, float z, int octaves, float persistence,
+__device__ float fbm3_dyn(const perm_t *perm, float x, float y, float z, int octaves, float persistence,
                           float lacunarity) {
     float value = 0.0f, amplitude = 1.0f, freq = 1.0f;
     for (int o = 0; o < octaves; ++o) {
@@ -122,7 +129,7 @@ __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f),
 // _generate_background_kernel (render.py:3332-3451); writes comp[0,1,2,3,4,11,12].
 __global__ __launch_bounds__(256) void background_kernel(float *__restrict__ comp, int n_r, int n_phi, int az_freq,
                                                          float az_shear, float r_inner, float r_outer, float t) {
-    __shared__ int perm[512];
+    __shared__ perm_t perm[1024];
     load_perm(perm);
     const int phi_i = blockIdx.x * blockDim.x + threadIdx.x;
     const int ri = blockIdx.y;
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(256) void mip_down_kernel(const float4 *__restrict_
 __global__ __launch_bounds__(256) void noise_eval_kernel(const float *__restrict__ coords, float *__restrict__ out,
                                                          long long n, int mode, int octaves, float persistence,
                                                          float lacunarity) {
-    __shared__ int perm[512];
+    __shared__ perm_t perm[1024];
     load_perm(perm);
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
