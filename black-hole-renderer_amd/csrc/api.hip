@@ -39,6 +39,12 @@ void activate_slot(bhr_ctx *ctx, int k) {
     ctx->d_final = f.d_final;
     ctx->d_final_u8 = f.d_final_u8;
     ctx->d_queue = f.d_queue;
+    ctx->d_glow_hw = f.d_glow_hw;          // allocated on first use by flare.hip, which stores them back into the slot
+    ctx->d_glow_wh = f.d_glow_wh;
+    ctx->d_flare_c0 = f.d_flare_c0;
+    ctx->d_flare_c12 = f.d_flare_c12;
+    ctx->d_flare_sums = f.d_flare_sums;
+    ctx->flare_glow_rows = f.flare_glow_rows;
     ctx->active_slot = k;
 }
 
@@ -73,7 +79,8 @@ int32_t alloc_slot(bhr_ctx *ctx, int k) {
 
 void free_slot(bhr_ctx *ctx, int k) {
     bhr_frame_slot &f = ctx->slots[k];
-    void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur, f.d_queue};
+    void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur, f.d_queue,
+                    f.d_glow_hw, f.d_glow_wh, f.d_flare_c0, f.d_flare_c12, f.d_flare_sums};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (f.done) (void)hipEventDestroy(f.done);
@@ -333,8 +340,8 @@ void bhr_destroy(bhr_ctx *ctx) {
     if (ctx->scene_ev) (void)hipEventDestroy(ctx->scene_ev);
     void *bufs[] = {ctx->d_skybox,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_noise_in,
-                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params, ctx->d_glow_hw, ctx->d_glow_wh,
-                    ctx->d_flare_c0, ctx->d_flare_c12, ctx->d_flare_prog, ctx->d_flare_sums, ctx->d_tile_order, ctx->d_row_steps, ctx->d_gather};
+                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params,
+                    ctx->d_flare_prog, ctx->d_tile_order, ctx->d_row_steps, ctx->d_gather};   // the flare's per-frame scratch belongs to the slots
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -542,11 +549,7 @@ int32_t render_on_slot(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags, int 
     if (flags & BHR_LENS_FLARE) {
         if (ctx->rows != ctx->cfg.height)
             return bhr_fail(BHR_ERR_INVALID, "bhr_render: the lens flare needs whole-frame sums; use bhr_group_render for row blocks");
-        // the flare's scratch buffers are shared by the slots: wait for the other frame's passes
-        for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q) {
-            bhr_frame_slot &o = ctx->slots[q];
-            if (q != k && o.in_flight && o.stream && o.stream != f.stream) BHR_HIP(hipStreamWaitEvent(f.stream, o.done, 0));
-        }
+        // every slot has its own flare scratch (glow, sums): the frames' flare passes overlap like the rest
         BHR_TRY(bhr_launch_flare_glow(ctx, true));
         BHR_TRY(bhr_launch_flare_sums(ctx));
         BHR_TRY(bhr_launch_flare_apply(ctx, nullptr));

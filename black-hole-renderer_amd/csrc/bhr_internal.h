@@ -86,6 +86,10 @@ struct bhr_frame_slot {
     float *d_bg, *d_disk, *d_hblur, *d_blur, *d_final;
     uint8_t *d_final_u8;
     unsigned int *d_queue;
+    // lens flare scratch of the frame (flare.hip): glow rows, their transpose, chunk sums, the three frame sums
+    float *d_glow_hw, *d_glow_wh, *d_flare_c0;
+    double *d_flare_c12, *d_flare_sums;
+    int64_t flare_glow_rows;
     hipEvent_t done;        // end of the slot's last bhr_render (and of frame work queued behind it: bhr_leave_frame)
     hipEvent_t march_done;  // end of its march: the last reader of the scene (bhr_enter_scene_write)
     int32_t allocated;

@@ -264,7 +264,9 @@ int build_tree(int off, int n, std::vector<int> &leaves, std::vector<int> &ops) 
     return a;
 }
 
-int32_t ensure_buffers(bhr_ctx *ctx, bool whole_frame) {
+// ctx->d_glow_* / d_flare_c* / d_flare_sums are the ACTIVE frame slot's (api.hip: activate_slot); what is allocated
+// here is stored back into the slot.  The tail program is read-only and shared.
+int32_t ensure_buffers_(bhr_ctx *ctx, bool whole_frame) {
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     const size_t want_rows = whole_frame ? (size_t)H : (size_t)ctx->rows;
     if (ctx->flare_glow_rows < (int64_t)want_rows) {
@@ -276,10 +278,14 @@ int32_t ensure_buffers(bhr_ctx *ctx, bool whole_frame) {
     if (!ctx->d_flare_sums) BHR_HIP(hipMalloc((void **)&ctx->d_flare_sums, 3 * sizeof(double)));
     if (whole_frame && !ctx->d_glow_wh) {
         const long long n = (long long)W * H;
-        const int n_chunks = (int)(n / CHUNK), tail = (int)(n % CHUNK);
+        const int n_chunks = (int)(n / CHUNK);
         BHR_HIP(hipMalloc((void **)&ctx->d_glow_wh, (size_t)n * sizeof(float)));
         BHR_HIP(hipMalloc((void **)&ctx->d_flare_c0, (size_t)(n_chunks + 1) * sizeof(float)));
         BHR_HIP(hipMalloc((void **)&ctx->d_flare_c12, (size_t)(n_chunks + 1) * 2 * sizeof(double)));
+    }
+    if (whole_frame && !ctx->d_flare_prog) {
+        const long long n = (long long)W * H;
+        const int tail = (int)(n % CHUNK);
         std::vector<int> leaves, ops;
         if (tail > 0) build_tree(0, tail, leaves, ops);
         if ((int)leaves.size() / 2 > MAX_TAIL_LEAVES) return bhr_fail(BHR_ERR_INVALID, "flare: tail tree has %d leaves", (int)leaves.size() / 2);
@@ -290,6 +296,18 @@ int32_t ensure_buffers(bhr_ctx *ctx, bool whole_frame) {
         BHR_HIP(hipMemcpy(ctx->d_flare_prog, prog.data(), prog.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     return BHR_OK;
+}
+
+int32_t ensure_buffers(bhr_ctx *ctx, bool whole_frame) {
+    const int32_t rc = ensure_buffers_(ctx, whole_frame);
+    bhr_frame_slot &f = ctx->slots[ctx->active_slot];
+    f.d_glow_hw = ctx->d_glow_hw;
+    f.d_glow_wh = ctx->d_glow_wh;
+    f.d_flare_c0 = ctx->d_flare_c0;
+    f.d_flare_c12 = ctx->d_flare_c12;
+    f.d_flare_sums = ctx->d_flare_sums;
+    f.flare_glow_rows = ctx->flare_glow_rows;
+    return rc;
 }
 
 }  // namespace
