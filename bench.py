@@ -62,6 +62,9 @@ def parse():
                     help="headline = ONE frame of --workload in --gpus row blocks (strong scaling; default for --workload 8k with N > 1)")
     ap.add_argument("--tile-workload", default="8k", choices=sorted(WORKLOADS) + ["none"],
                     help="frame of the row-block (strong-scaling) leg reported beside the headline; 'none' skips it")
+    ap.add_argument("--video-frames", type=int, default=300,
+                    help="informational leg at N = 1: frames of the video driver's loop (configs[4]: orbit, lifecycle texture "
+                         "every frame, PNG files written); 0 skips it")
     ap.add_argument("--math", default=None, choices=["fast", "strict"], help="march arithmetic (default: the renderer's)")
     return ap.parse_args()
 
@@ -140,6 +143,29 @@ def tile_leg(wl, n, frames, math=None, warmup=3):
     finally:
         for t in tiles:
             t.close()
+
+
+def video_leg(n_frames):
+    """BASELINE.json configs[4] on this GPU: drivers.render_video at fhd (orbit camera, populations ticking, texture
+    regenerated every frame, PNG frames encoded on the device and written to a temporary directory).  Informational:
+    reported beside the headline, never as `value`."""
+    import shutil, tempfile
+    from bhr_amd import drivers
+    tmp = tempfile.mkdtemp(prefix="bhr_bench_video_")
+    try:
+        r, _, _, _ = drivers.make_renderer(1920, 1080, [6, 0, 0.5], 90, n_stars=6000)
+        t0 = time.perf_counter()
+        drivers.render_video(r, 1920, 1080, n_frames=n_frames, fps=30, output_path=os.path.join(tmp, "v.mp4"), fov=90,
+                             static_cam_pos=[6, 0, 0.5], orbit=True, assemble=False, video_stream="off")
+        dt = time.perf_counter() - t0
+        files = [f for f in os.listdir(drivers._frames_dir(os.path.join(tmp, "v.mp4"))) if f.endswith(".png")]
+        size = sum(os.path.getsize(os.path.join(drivers._frames_dir(os.path.join(tmp, "v.mp4")), f)) for f in files)
+        r.close()
+        return {"fps": n_frames / dt, "frames": n_frames, "png_files": len(files), "mb_per_frame": size / max(len(files), 1) / 1e6,
+                "png_encoder": "device", "what": "render_video at 1920x1080: lifecycle init + every frame's populations, "
+                "background / entity / compose passes, march, bloom, PNG file on disk"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -335,6 +361,11 @@ def main():
                              "note": "informational A/B in the same process; `value` above is the default (parity-certified) arithmetic"}
         if tile is not None:
             out["tile_scaling"] = tile
+        if args.video_frames > 0 and world == 1 and not args.no_other_math:
+            try:
+                out["video_loop"] = video_leg(args.video_frames)
+            except Exception as e:      # the headline stands on its own
+                out["video_loop"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, sky, tex)
         sys.stdout.flush()
