@@ -26,6 +26,11 @@ def test_cli_defaults_match_reference():
     assert (b.disk_inner_radius, b.disk_outer_radius, b.resolution, b.step_size) == (3.0, 9.0, "8k", 0.05)
     assert b.video and b.orbit and b.n_frames == 12 and b.pov == [1.0, 2.0, 3.0]
     assert cli.RESOLUTIONS["8k"] == (7680, 4320) and cli.RESOLUTIONS["fhd"] == (1920, 1080)
+    # additions of this build: where the video frames are PNG-encoded, and the yuv420p stream
+    assert a.png_encoder == "device" and a.video_stream == "auto"
+    assert cli.parse_args(["--png_encoder", "host", "--video_stream", "y4m"]).png_encoder == "host"
+    with pytest.raises(SystemExit):
+        cli.parse_args(["--png_encoder", "zlib"])
 
 
 @pytest.mark.parametrize("argv,msg", [

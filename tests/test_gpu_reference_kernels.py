@@ -217,3 +217,39 @@ def test_e2e_whole_pipeline_vs_the_reference_s_render_image(hip_lib, capsys):
     np.testing.assert_allclose(row_stats, g["row_stats"], rtol=5e-3, atol=1e-4)
     assert np.median(dt) <= 1e-5 and dt.max() <= 1e-3          # measured: median 2.8e-6, max 9.8e-5
     assert (e <= 1e-5).all() and (e <= NORTH_STAR).all(), e    # measured 1.3-2.0e-6; north star 1e-4
+
+
+def test_video_loop_vs_the_reference_s_video_loop(hip_lib, capsys):
+    """The video driver's loop on the device -- populations ticking, background / entity / compose passes at t > 0,
+    orbit camera, march, bloom -- against frames 0, 2 and 7 of the reference's own loop (`_advance_lifecycle_frame` +
+    `render`, render.py:4436-4453) on the same scene.  Same sources of difference as the still e2e frame: libm
+    rounding in the background generator moves texels by ~1e-4, the frame inherits that through the bilinear look-ups."""
+    from bhr_amd import HipRenderer, drivers
+    from bhr_amd.camera import orbit_position
+    from test_reference_kernels import E2E_KW, load_video
+    g, sky = load_video()
+    n_r, n_phi = (int(v) for v in g["tex_shape"])
+    r = HipRenderer(320, 180, sky, np.zeros((n_r, n_phi, 4), np.float32), **E2E_KW)
+    fac = drivers.init_lifecycle_system(r, n_r, n_phi, seed=42)
+    dt = float(g["speed"])
+    stored = [int(f) for f in g["frames"]]
+    lines = []
+    for frame in range(max(stored) + 1):
+        drivers.advance_lifecycle_frame(r, fac, frame * dt, dt, recompute_stats=(frame % 60 == 0), compose=frame in stored)
+        if frame not in stored:
+            continue
+        cam = orbit_position([6.0, 0.0, 0.5], frame, int(g["n_frames"]), float(g["orbit_degrees"]))
+        np.testing.assert_allclose(cam, g[f"cam_{frame}"], rtol=0, atol=1e-12)
+        img = r.render(cam, 60)
+        tex = r.disk_texture_field.to_numpy()
+        alive = [len(fac[k].alive_entities) for k in ("filament", "hotspot", "rt_spike")]
+        assert alive == list(g[f"alive_{frame}"]), (frame, alive)
+        dtx = np.abs(tex - g[f"disk_tex_{frame}"])
+        e = _rmse_c(img, g[f"final_{frame}"])
+        lines.append(f"[video] frame {frame}: texture max {dtx.max():.3g} median {np.median(dtx):.3g}; frame RMSE {e}, "
+                     f"max {np.abs(img - g[f'final_{frame}']).max():.3g}")
+        assert np.median(dtx) <= 1e-5 and dtx.max() <= 2e-3, (frame, np.median(dtx), dtx.max())
+        assert (e <= 2e-5).all() and (e <= NORTH_STAR).all(), (frame, e)
+    r.close()
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))

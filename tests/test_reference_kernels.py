@@ -262,3 +262,29 @@ def test_e2e_frame_march_and_bloom_on_the_reference_s_texture(oracle):
     d = np.abs(out.astype(np.float64) - g["final"])
     assert d.max() <= 2e-5 and np.sqrt((d ** 2).mean()) <= 5e-7, (d.max(), np.sqrt((d ** 2).mean()))
     assert g["final"].max() > 0.5 and g["disk_tex"][..., 3].max() > 0.5
+
+
+# --------------------------------------------------------------------------- frames of the reference's video loop
+def load_video():
+    """tests/golden/video_ref.npz: frames of the reference's own video loop on the e2e scene (24-frame orbit; stored
+    frames 0, 2 and 7), every kernel executed as binary32 Python (make_video_golden.py).  -> fixture, sky."""
+    import hashlib as _h
+    from bhr_amd.skybox import generate_skybox
+    g = np.load(os.path.join(GOLD, "video_ref.npz"))
+    sky = generate_skybox(2048, 1024, seed=42, n_stars=int(g["n_stars"]))
+    assert _h.sha256(np.ascontiguousarray(sky).tobytes()).hexdigest() == str(g["sky_sha256"])
+    return g, sky
+
+
+def test_video_frames_march_and_bloom_on_the_reference_s_textures(oracle):
+    """Every stored frame of the reference's video loop: the oracle's march + bloom from the orbit camera on the
+    texture the reference's lifecycle / background / compose kernels produced for that frame."""
+    g, sky = load_video()
+    for f in g["frames"]:
+        o = oracle.OracleRenderer(320, 180, sky, g[f"disk_tex_{f}"], **E2E_KW)
+        out = o.render(list(g[f"cam_{f}"]), 60)
+        d = np.abs(out.astype(np.float64) - g[f"final_{f}"])
+        assert d.max() <= 5e-5 and np.sqrt((d ** 2).mean()) <= 1e-6, (int(f), d.max(), np.sqrt((d ** 2).mean()))
+    frames = [int(f) for f in g["frames"]]
+    assert np.abs(g[f"final_{frames[0]}"] - g[f"final_{frames[-1]}"]).mean() > 1e-3          # the camera really moved
+    assert np.abs(g[f"disk_tex_{frames[0]}"] - g[f"disk_tex_{frames[1]}"]).max() > 1e-3      # and so did the disk
