@@ -42,6 +42,8 @@ constexpr int kHdrWords = 64;      // room for a block header (<= 2048 bits)
 constexpr int kThreads = 256;
 constexpr int kScanThreads = 1024;
 constexpr uint32_t kPoly = 0xEDB88320u;
+static_assert(kThreads == 256, "one thread per literal in the plan kernel, one per CRC table entry in the encoder");
+static_assert(kTables == 16, "len_nibbles packs one 4-bit length per menu entry into 64 bits");
 
 struct PngTables {
     uint32_t code[kTables][260];   // (bit-reversed code << 4) | length, indexed by symbol
