@@ -25,7 +25,7 @@ SYMBOLS = (
     "bhr_fill_comp_slice", "bhr_set_compose_stats", "bhr_compose_texture", "bhr_eval_noise", "bhr_render",
     "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_timing_reset", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_read_gathered", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities", "bhr_accumulate_population",
     "bhr_stats_prepare", "bhr_stats_select", "bhr_stats_row_statistics",
-    "bhr_png_bound", "bhr_png_encode", "bhr_png_write", "bhr_png_device_bound", "bhr_png_encode_device", "bhr_png_device_menu",
+    "bhr_png_bound", "bhr_png_encode", "bhr_png_write", "bhr_png_device_bound", "bhr_png_device_max_width", "bhr_png_encode_device", "bhr_png_device_menu",
     "bhr_sink_create", "bhr_sink_submit", "bhr_sink_drain",
     "bhr_sink_destroy", "bhr_y4m_open", "bhr_y4m_submit", "bhr_y4m_drain", "bhr_y4m_close",
 )
@@ -117,6 +117,7 @@ def load() -> C.CDLL:
     lib.bhr_png_encode.argtypes = [U8, I32, I32, I32, I32, U8, I64, C.POINTER(I64)]
     lib.bhr_png_write.argtypes = [C.c_char_p, U8, I32, I32, I32, I32]
     lib.bhr_png_device_bound.argtypes = [I32, I32]
+    lib.bhr_png_device_max_width.argtypes = []
     lib.bhr_png_encode_device.argtypes = [P, U8, I64, C.POINTER(I64)]
     U32P = C.POINTER(C.c_uint32)
     lib.bhr_png_device_menu.argtypes = [I32, U32P, U32P, U32P, C.POINTER(I32)]

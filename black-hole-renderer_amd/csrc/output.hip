@@ -482,6 +482,9 @@ int32_t bhr_png_write(const char *path, const uint8_t *rgb, int32_t w, int32_t h
 int32_t bhr_sink_create(bhr_ctx *ctx, int32_t slots, int32_t workers, int32_t level, bhr_sink **out) {
     if (!ctx || !out || slots < 1 || slots > 256 || workers < 1 || workers > 256 || level < BHR_PNG_DEVICE || level > 9)
         return bhr_fail(BHR_ERR_INVALID, "bhr_sink_create: bad argument (slots %d, workers %d, level %d)", slots, workers, level);
+    if (level == BHR_PNG_DEVICE && ctx->cfg.width > bhr_png_device_max_width())
+        return bhr_fail(BHR_ERR_INVALID, "bhr_sink_create: the device PNG encoder takes frames up to %d pixels wide, this one has %d; "
+                        "use a zlib level (host encoder)", bhr_png_device_max_width(), ctx->cfg.width);
     BHR_HIP(hipSetDevice(ctx->cfg.device));
     bhr_sink *s = new bhr_sink();
     s->ctx = ctx;

@@ -648,6 +648,21 @@ int chunk_words_for(int n) { return (int)(((size_t)n + 1) * 9 / 8 / 4 + 96); }  
 
 }  // namespace
 
+// Widest frame the encode kernel can hold: two padded rows (or the chunk) + the filtered row in 150 KB of LDS.
+extern "C" int32_t bhr_png_device_max_width(void) {
+    int lo = 1, hi = 1 << 16;
+    auto fits = [](int w) {
+        const size_t n = 3 * (size_t)w, npad = (n + 15) & ~(size_t)15;
+        const size_t rows = 2 * (16 + npad), chunk = 4 * (size_t)chunk_words_for((int)n);
+        return ((std::max(rows, chunk) + 15) & ~(size_t)15) + ((n + 1 + 15) & ~(size_t)15) <= 150 * 1024;
+    };
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (fits(mid)) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 extern "C" int64_t bhr_png_device_bound(int32_t w, int32_t h) {
     if (w <= 0 || h <= 0) return 0;
     return (int64_t)h * (4 * (int64_t)chunk_words_for(3 * w)) + 64;
@@ -714,8 +729,9 @@ int32_t bhr_launch_png_encode(bhr_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_out
     const size_t row_buf = 16 + (size_t)npad;                       // kRowPrefix + padded row (row_stride)
     const size_t lds_plan = 2 * row_buf;
     const size_t lds_enc = ((std::max(2 * row_buf, (size_t)4 * cwords) + 15) & ~(size_t)15) + ((n + 1 + 15) & ~15);
-    if (lds_enc > 150 * 1024)
-        return bhr_fail(BHR_ERR_INVALID, "device PNG encoder: a scanline of %d bytes does not fit LDS (%zu bytes needed)", n, lds_enc);
+    if (bhr_png_device_max_width() < ctx->cfg.width)
+        return bhr_fail(BHR_ERR_INVALID, "device PNG encoder: a scanline of %d pixels does not fit LDS (at most %d); use the host encoder",
+                        ctx->cfg.width, bhr_png_device_max_width());
     if (!d->lds_attr) {
         BHR_HIP(hipFuncSetAttribute((const void *)png_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         BHR_HIP(hipFuncSetAttribute((const void *)png_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -148,6 +148,11 @@ def render_image(width: int, height: int, cam_pos: List[float], fov: float, step
     return img
 
 
+def _lib_max_png_width() -> int:
+    from . import _lib
+    return int(_lib.load().bhr_png_device_max_width())
+
+
 def _frames_dir(output_path: str) -> str:
     name = ".frames_" + hashlib.md5(output_path.encode()).hexdigest()[:16]
     return os.path.join(os.path.dirname(output_path), name)
@@ -232,6 +237,9 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
     rendered = 0
     # the reference saves through a 2-thread PIL pool (render.py:4412-4413); here the frame is quantised
     # on the device, copied into a pinned ring and encoded by worker threads while the next frames render
+    if png_level == DEVICE and width > _lib_max_png_width():
+        print(f"  frames wider than {_lib_max_png_width()} pixels are PNG-encoded on the host (zlib level {VIDEO_LEVEL})")
+        png_level = VIDEO_LEVEL
     if png_level == DEVICE and sink_workers <= 0:
         sink_workers = 4                                 # copy + write only
     sink = FrameSink(renderer, slots=sink_slots, workers=sink_workers, level=png_level)

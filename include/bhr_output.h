@@ -36,6 +36,9 @@ BHR_API int32_t bhr_png_write(const char *path, const uint8_t *rgb, int32_t w, i
  *     finished bytes (an exact-length copy on their own stream) and write the file. */
 #define BHR_PNG_DEVICE (-1)
 BHR_API int64_t bhr_png_device_bound(int32_t w, int32_t h);
+/* Widest frame the device encoder takes (one scanline is coded by one block out of LDS): 17 000-odd pixels.
+ * bhr_png_encode_device and bhr_sink_create(.., BHR_PNG_DEVICE, ..) fail with BHR_ERR_INVALID beyond it. */
+BHR_API int32_t bhr_png_device_max_width(void);
 BHR_API int32_t bhr_png_encode_device(bhr_ctx *ctx, uint8_t *out, int64_t cap, int64_t *out_len);
 /* Entry k of the code menu, as the kernels use it (host only, no GPU needed; for inspection and tests):
  * codes[257] = (bit-reversed code << 4) | length for literals 0..255 and end-of-block, hdr_words[64] / *hdr_bits =

@@ -82,6 +82,12 @@ def test_every_menu_header_inflates(hip_lib):
         assert d.eof and got == b"".join(rows), f"menu entry {k}"
 
 
+def test_device_encoder_width_limit_is_beyond_every_baseline_size(hip_lib):
+    from bhr_amd import _lib
+    w = _lib.load().bhr_png_device_max_width()
+    assert 2 * 7680 <= w < 20000                  # a scanline lives in LDS: ~17 000 pixels; 8k is 7680
+
+
 def _parse_png(data):
     """-> (width, height, [IDAT payloads]); checks signature, chunk order and every CRC."""
     assert data[:8] == b"\x89PNG\r\n\x1a\n"
@@ -248,4 +254,26 @@ def test_device_png_of_a_row_block_context(hip_lib):
     img = np.asarray(Image.open(io.BytesIO(png_encode_device(r))).convert("RGB"))
     np.testing.assert_array_equal(img, r.read_final_u8())
     assert img.shape == (64, 256, 3)
+    r.close()
+
+
+@pytest.mark.gpu
+def test_widest_frame_and_the_error_beyond_it(hip_lib):
+    """The widest frame the encoder takes (150 KB of LDS per scanline) decodes correctly; one pixel more is refused at
+    sink creation and at encode time with a message naming the host encoder."""
+    from PIL import Image
+    import io
+    from bhr_amd import HipRenderer, _lib
+    from bhr_amd.output import DEVICE, FrameSink, png_encode_device
+    wmax = _lib.load().bhr_png_device_max_width()
+    r = HipRenderer(wmax, 3, scenes.analytic_skybox(), scenes.noisy_disk())
+    r.render_async([6, 0, 0.5], 90)
+    np.testing.assert_array_equal(np.asarray(Image.open(io.BytesIO(png_encode_device(r))).convert("RGB")), r.read_final_u8())
+    r.close()
+    r = HipRenderer(wmax + 1, 3, scenes.analytic_skybox(), scenes.noisy_disk())
+    r.render_async([6, 0, 0.5], 90)
+    with pytest.raises(ValueError, match="host encoder"):
+        png_encode_device(r)
+    with pytest.raises(ValueError, match="host encoder"):
+        FrameSink(r, slots=2, workers=1, level=DEVICE)
     r.close()
