@@ -17,6 +17,9 @@ ONE JSON line.
             hipMemcpyPeerAsync) is timed at every N as well and reported as `tile_scaling` (strong scaling);
             `--workload 8k --gpus N` (or --strong) makes that leg the headline;
 * value     total ray-steps of all ranks / max-over-ranks wall time of the K timed steps.
+* beside it (never as `value`): `kernel_ms` / `roofline` / `roofline_valu` from isolated launches of the same scene,
+            `other_math` (the opt-in fast arithmetic), `tile_scaling`, `video_loop` (N = 1: frames of the video driver's
+            loop, configs[4], PNG files written) and `cpu_baseline` (N = 1: the CPU restatement on the host's threads).
 """
 import argparse
 import json
