@@ -277,3 +277,24 @@ def test_widest_frame_and_the_error_beyond_it(hip_lib):
     with pytest.raises(ValueError, match="host encoder"):
         FrameSink(r, slots=2, workers=1, level=DEVICE)
     r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(1920, 1080), (7680, 4320)])
+def test_whole_frames_at_the_baseline_sizes(size, hip_lib):
+    """fhd and 8k frames (analytic textures of bhr_amd.scenes): every scanline's chunk CRC, the Adler-32 of the stream and
+    the decoded pixels; the file stays far below the raw size."""
+    from PIL import Image
+    import io
+    from bhr_amd.output import png_encode_device
+    Image.MAX_IMAGE_PIXELS = None
+    w, h = size
+    r = _frame(w, h, step_size=0.1 if w < 4000 else 0.05)
+    data = png_encode_device(r)
+    want = r.read_final_u8()
+    pw, ph, idat = _parse_png(data)
+    assert (pw, ph) == (w, h) and len(idat) == h
+    assert len(zlib.decompress(b"".join(idat))) == h * (3 * w + 1)
+    np.testing.assert_array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), want)
+    assert len(data) < 0.5 * want.nbytes
+    r.close()
