@@ -68,7 +68,10 @@ def parse():
     ap.add_argument("--video-frames", type=int, default=300,
                     help="informational leg at N = 1: frames of the video driver's loop (configs[4]: orbit, lifecycle texture "
                          "every frame, PNG files written); 0 skips it")
-    ap.add_argument("--math", default=None, choices=["fast", "strict"], help="march arithmetic (default: the renderer's)")
+    ap.add_argument("--math", default=None, choices=["fast", "strict", "hybrid"], help="march arithmetic (default: the renderer's)")
+    ap.add_argument("--spin-up-ms", type=float, default=60.0,
+                    help="un-timed frames rendered for this long BEFORE the --warmup steps: the scene set-up leaves the GPU idle "
+                         "and its clocks low, and they take ~20 ms of load to come back (tools/exp_bench_ramp.py)")
     return ap.parse_args()
 
 
@@ -143,6 +146,73 @@ def tile_leg(wl, n, frames, math=None, warmup=3):
                 "exchange": "bloom halo rows + final gather onto device 0 with hipMemcpyPeerAsync, no collective",
                 "driven_by": "rank 0 drives all devices in one process (bhr_group_render); the other ranks wait at a host barrier",
                 "scene": note}
+    finally:
+        for t in tiles:
+            t.close()
+
+
+def tile_tail_leg(wl, n_tiles=8, math=None, reps=8, verbose=False, schedules=("pipelined",), gathers=("peer_u8",)):
+    """What ONE GPU can show of the N-GPU row-block leg: the frame of ``wl`` is cut into ``n_tiles`` cost-balanced row
+    blocks, all on this device; after one full render every tile in turn is rendered ALONE (the other tiles keep their
+    buffers: bhr_group_render_subset) and timed end to end -- first march launch .. its rows landed in the gather buffer
+    on tile 0, halo pulls from the resting neighbours included -- against its march kernel alone.  On N real GPUs the
+    tiles run at the same time, so the frame takes what the slowest tile takes: predicted efficiency = (one-GPU frame
+    time) / (n_tiles x slowest tile).  Copies stay on this device (HBM, not xGMI): the 14 MB halo pull and the 12 MB u8
+    push would take ~0.09 / ~0.08 ms on a 153 GB/s link, under the march / the next chunk's V pass in the pipelined
+    schedule."""
+    from bhr_amd import multigpu, workloads
+    tiles, blocks, note = workloads.make_tiles(wl, [0] * n_tiles, math=math)
+    cam, fov = wl["cam_pos"], wl["fov"]
+    out = {"workload": f"{wl['width']}x{wl['height']} step_size {wl['step_size']}, {n_tiles} row blocks on one device",
+           "row_blocks": [list(b) for b in blocks], "per_tile": [], "reps": reps}
+    try:
+        for sched in schedules:
+            for g in gathers:
+                for _ in range(2):
+                    multigpu.group_render(tiles, cam, fov, gather=g, schedule=sched)
+                t0 = time.perf_counter()
+                for _ in range(max(reps // 2, 2)):
+                    multigpu.group_render(tiles, cam, fov, gather=g, schedule=sched)
+                out[f"all_tiles_one_device_ms_{sched}_{g}"] = (time.perf_counter() - t0) / max(reps // 2, 2) * 1e3
+        # march alone, per tile (its own kernel bracket, nothing else on the device)
+        march_alone = []
+        for t in tiles:
+            for _ in range(2):
+                t.render_async(cam, fov, skip_bloom=True)
+            ms = []
+            for _ in range(reps):
+                t.render_async(cam, fov, skip_bloom=True)
+                ms.append(t.counters()["march_ms"])
+            march_alone.append(float(np.median(ms)))
+        multigpu.group_render(tiles, cam, fov, gather=gathers[0], schedule=schedules[0])      # every tile's buffers current again
+        for k, t in enumerate(tiles):
+            live = [1 if q == k else 0 for q in range(n_tiles)]
+            row = {"tile": k, "rows": list(blocks[k]), "march_alone_ms": march_alone[k]}
+            for sched in schedules:
+                for g in gathers:
+                    for _ in range(2):
+                        multigpu.group_render(tiles, cam, fov, gather=g, schedule=sched, live=live)
+                    e2e, wall = [], []
+                    for _ in range(reps):
+                        t0 = time.perf_counter()
+                        multigpu.group_render(tiles, cam, fov, gather=g, schedule=sched, live=live)
+                        wall.append((time.perf_counter() - t0) * 1e3)
+                        e2e.append(t.counters()["frame_ms"])
+                    row[f"e2e_ms_{sched}_{g}"] = float(np.median(e2e))
+                    row[f"wall_ms_{sched}_{g}"] = float(np.median(wall))
+            out["per_tile"].append(row)
+            if verbose:
+                print(row, flush=True)
+        key = f"e2e_ms_{schedules[0]}_{gathers[0]}"
+        slow = max(out["per_tile"], key=lambda r: r[key])
+        out["schedule"], out["gather"] = schedules[0], gathers[0]
+        out["slowest_tile"] = slow["tile"]
+        out["tile_ms"] = slow[key]
+        out["tile_march_alone_ms"] = slow["march_alone_ms"]
+        out["tile_tail_ms"] = slow[key] - slow["march_alone_ms"]
+        out["tile_tail_frac"] = out["tile_tail_ms"] / slow[key]
+        out["scene"] = note
+        return out
     finally:
         for t in tiles:
             t.close()
@@ -234,6 +304,17 @@ def main():
     # frames sharded round-robin over ranks (configs[4]); the camera is the static default pov
     compaction = args.persistent
     flare = bool(wl.get("lens_flare", False))       # configs[2]: on the device, inside the timed step
+    # Spin-up (un-timed, before the warm-up steps): after the scene set-up -- hundreds of ms of host work with an idle GPU
+    # -- the shader clock is low and needs ~20 ms of load to come back; 5 warm-up frames are 4 ms.  Measured on this
+    # scene (tools/exp_bench_ramp.py, profiles/r03_bench_ramp.md): the march takes 0.77 ms in the first timed frame of a
+    # 20-step run straight after set-up, 0.74 in the tenth, 0.675 from ~25 ms on.
+    n_spin = 0
+    t_spin = time.perf_counter()
+    while (time.perf_counter() - t_spin) * 1e3 < args.spin_up_ms:
+        for _ in range(8):
+            renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
+        renderer.sync()
+        n_spin += 8
     for _ in range(args.warmup):
         renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
     renderer.timing_reset()
@@ -333,6 +414,8 @@ def main():
                        "sharding": "independent frames per rank, no collective",
                        "march_schedule": "persistent+refill" if args.persistent else "tile",
                        "march_math": renderer.math, "frame_slots": renderer.frame_slots,
+                       "spin_up": f"{n_spin} un-timed frames ({args.spin_up_ms:g} ms) before the {args.warmup} warm-up steps",
+
                        "ray_steps_per_frame": int(steps_per_frame), "steps_per_ray": steps_per_frame / pixels},
             "kernel_ms": {"march": march_ms, "bloom_combine_flare" if flare else "bloom_and_combine": bloom_ms, "frames_timed": k_frames,
                           "march_vgprs": c["march_vgprs"],

@@ -1,6 +1,7 @@
 // api.hip -- the extern "C" surface declared in include/bhr.h.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -89,7 +90,9 @@ void free_slot(bhr_ctx *ctx, int k) {
     memset(&f, 0, sizeof(f));
 }
 
-int32_t ensure_pinned(bhr_ctx *ctx, size_t bytes) {
+int32_t ensure_pinned(bhr_ctx *ctx, size_t bytes) { return bhr_ensure_pinned(ctx, bytes); }
+}  // namespace
+int32_t bhr_ensure_pinned(bhr_ctx *ctx, size_t bytes) {
     if (ctx->h_pinned_bytes >= bytes) return BHR_OK;
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     ctx->h_pinned = nullptr;
@@ -98,6 +101,7 @@ int32_t ensure_pinned(bhr_ctx *ctx, size_t bytes) {
     ctx->h_pinned_bytes = bytes;
     return BHR_OK;
 }
+namespace {
 
 // device -> caller memory through the pinned staging buffer (synchronises the stream)
 int32_t download(bhr_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
@@ -312,9 +316,9 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
         hipMemsetAsync(ctx->d_steps_ring, 0, sizeof(unsigned long long) * BHR_TIMING_RING * BHR_STEP_CELL, ctx->stream) != hipSuccess)
         return bail(bhr_fail(BHR_ERR_HIP, "hipMemsetAsync failed"));
     int32_t v = 0, l = 0;
-    if (cfg->math_mode != BHR_MATH_FAST && cfg->math_mode != BHR_MATH_STRICT)
+    if (cfg->math_mode != BHR_MATH_FAST && cfg->math_mode != BHR_MATH_STRICT && cfg->math_mode != BHR_MATH_HYBRID)
         return bail(bhr_fail(BHR_ERR_INVALID, "bhr_create: math_mode %d", cfg->math_mode));
-    if ((cfg->math_mode == BHR_MATH_STRICT ? (cfg->anti_alias != 0 ? bhr_march_resources_strict_ilp(&v, &l, 1)
+    if ((cfg->math_mode != BHR_MATH_FAST ? (cfg->anti_alias != 0 ? bhr_march_resources_strict_ilp(&v, &l, 1)
                                                                    : bhr_march_resources_strict_ilp(&v, &l, 0))
                                            : bhr_march_resources(&v, &l, cfg->anti_alias != 0)) == BHR_OK) {
         ctx->counters.march_vgprs = v;
@@ -337,6 +341,10 @@ void bhr_destroy(bhr_ctx *ctx) {
     for (int k = 0; k < BHR_MAX_FRAME_SLOTS; ++k) free_slot(ctx, k);
     bhr_png_dev_free(ctx);
     bhr_population_free(ctx);
+    bhr_hybrid_free(ctx);
+    bhr_pipe_free(ctx);
+    if (ctx->d_gather_u8) (void)hipFree(ctx->d_gather_u8);
+    free(ctx->h_tile_order);
     if (ctx->scene_ev) (void)hipEventDestroy(ctx->scene_ev);
     void *bufs[] = {ctx->d_skybox,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_noise_in,
@@ -624,7 +632,9 @@ int32_t bhr_bloom(bhr_ctx *ctx) {
     if (ctx->rows != ctx->cfg.height)
         return bhr_fail(BHR_ERR_INVALID, "bhr_bloom: needs a whole-frame context (rows %d of %d)", ctx->rows, ctx->cfg.height);
     BHR_TRY(use_device(ctx));
-    BHR_TRY(bhr_launch_bloom_h(ctx));
+    const char *only = getenv("BHR_BLOOM_ONLY");               // "h" / "v": one pass alone (tools/exp_bloom.py times them)
+    if (!(only && only[0] == 'v')) BHR_TRY(bhr_launch_bloom_h(ctx));
+    if (only && only[0] == 'h') return BHR_OK;
     return bhr_launch_bloom_v(ctx, 1);
 }
 
@@ -726,6 +736,20 @@ int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {
     return BHR_OK;
 }
 
+int32_t bhr_timing_dump(bhr_ctx *ctx, float *out, int32_t n) {
+    if (!ctx || !out || n <= 0) return bhr_fail(BHR_ERR_INVALID, "bhr_timing_dump: bad argument");
+    BHR_TRY(use_device(ctx));
+    BHR_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t have = ctx->ring_head < BHR_TIMING_RING - BHR_MAX_FRAME_SLOTS ? ctx->ring_head : BHR_TIMING_RING - BHR_MAX_FRAME_SLOTS;
+    if (n > have) return bhr_fail(BHR_ERR_INVALID, "bhr_timing_dump: %d frames asked, %lld on record", n, (long long)have);
+    const hipEvent_t origin = ctx->ring_ev[(int)((ctx->ring_head - n) % BHR_TIMING_RING) * 3];
+    for (int k = 0; k < n; ++k) {
+        const int slot = (int)((ctx->ring_head - n + k) % BHR_TIMING_RING);
+        for (int e = 0; e < 3; ++e) out[k * 3 + e] = ev_ms(origin, ctx->ring_ev[slot * 3 + e]);
+    }
+    return BHR_OK;
+}
+
 int32_t bhr_selftest(bhr_ctx *ctx, uint64_t out[4]) {
     if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_selftest: bad argument");
     BHR_TRY(use_device(ctx));
@@ -753,165 +777,6 @@ int32_t bhr_timing_reset(bhr_ctx *ctx) {
     BHR_HIP(hipMemsetAsync(ctx->d_steps_ring, 0, sizeof(unsigned long long) * BHR_TIMING_RING * BHR_STEP_CELL, ctx->stream));
     BHR_HIP(hipStreamSynchronize(ctx->stream));
     ctx->ring_head = 0;
-    return BHR_OK;
-}
-
-// Direct xGMI copies between the tiles' devices: without peer access hipMemcpyPeerAsync stages through
-// host memory.  Tried once per ordered device pair; a refusal is not an error (the staged copy still works).
-static void enable_peer_access(bhr_ctx **ctxs, int32_t n) {
-    static bool tried[64][64];
-    for (int k = 0; k < n; ++k)
-        for (int q = 0; q < n; ++q) {
-            const int a = ctxs[k]->cfg.device, b = ctxs[q]->cfg.device;
-            if (a == b || a < 0 || b < 0 || a >= 64 || b >= 64 || tried[a][b]) continue;
-            tried[a][b] = true;
-            int can = 0;
-            if (hipSetDevice(a) != hipSuccess || hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
-                (void)hipGetLastError();
-                continue;
-            }
-            if (hipDeviceEnablePeerAccess(b, 0) != hipSuccess) (void)hipGetLastError();   // e.g. already enabled
-        }
-}
-
-int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host) {
-    if (!ctxs || n <= 0 || !cam) return bhr_fail(BHR_ERR_INVALID, "bhr_group_render: bad argument");
-    const int W = ctxs[0]->cfg.width, H = ctxs[0]->cfg.height;
-    int expect = 0;
-    for (int k = 0; k < n; ++k) {
-        if (!ctxs[k]) return bhr_fail(BHR_ERR_INVALID, "bhr_group_render: null ctx %d", k);
-        if (ctxs[k]->cfg.width != W || ctxs[k]->cfg.height != H || ctxs[k]->cfg.row0 != expect)
-            return bhr_fail(BHR_ERR_INVALID, "bhr_group_render: tile %d does not continue the image (row0 %d, expected %d)", k, ctxs[k]->cfg.row0, expect);
-        expect = ctxs[k]->cfg.row1;
-    }
-    if (expect != H) return bhr_fail(BHR_ERR_INVALID, "bhr_group_render: tiles cover %d of %d rows", expect, H);
-    enable_peer_access(ctxs, n);
-    const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
-    const size_t R = ctxs[0]->bloom_R;
-
-    // phase 1: every tile marches and H-blurs its own rows, concurrently.  With several devices the launches are
-    // submitted by one host thread per tile: a single thread needs ~30 us per device (hipSetDevice + memset + three
-    // launches + events), which at 8 devices starts the last march a quarter of a millisecond late in a 3 ms frame.
-    auto phase1 = [&](int k) -> int32_t {
-        BHR_TRY(use_device(ctxs[k]));
-        ctxs[k]->cur_slot = -1;
-        ctxs[k]->last_slot = -1;
-        BHR_TRY(bhr_launch_march(ctxs[k], cam, flags));
-        if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctxs[k]));
-        BHR_HIP(hipEventRecord(ctxs[k]->ev[3], ctxs[k]->stream));
-        return BHR_OK;
-    };
-    bool distinct_devices = n > 1;
-    for (int k = 1; k < n && distinct_devices; ++k)
-        for (int q = 0; q < k; ++q)
-            if (ctxs[k]->cfg.device == ctxs[q]->cfg.device) distinct_devices = false;
-    if (const char *e = getenv("BHR_GROUP_THREADS")) distinct_devices = n > 1 && atoi(e) != 0;   // test knob: force / forbid
-    if (distinct_devices) {
-        std::vector<int32_t> rcs((size_t)n, BHR_OK);
-        std::vector<std::string> errs((size_t)n);
-        std::vector<std::thread> th;
-        for (int k = 1; k < n; ++k)
-            th.emplace_back([&, k] { rcs[(size_t)k] = phase1(k); if (rcs[(size_t)k] != BHR_OK) errs[(size_t)k] = bhr_last_error(); });
-        rcs[0] = phase1(0);
-        if (rcs[0] != BHR_OK) errs[0] = bhr_last_error();
-        for (auto &t : th) t.join();
-        for (int k = 0; k < n; ++k)
-            if (rcs[(size_t)k] != BHR_OK) return bhr_fail(rcs[(size_t)k], "tile %d: %s", k, errs[(size_t)k].c_str());
-    } else {
-        for (int k = 0; k < n; ++k) BHR_TRY(phase1(k));
-    }
-    // phase 2: halo exchange of the H-blurred rows (planar (3, rows + 2R, W)); the V pass of
-    // tile k needs up to R rows from each neighbour.  Peer copies ride the receiving stream
-    // after the producer's event.
-    if (with_bloom && n > 1) {
-        for (int k = 0; k < n; ++k) {
-            bhr_ctx *me = ctxs[k];
-            BHR_TRY(use_device(me));
-            const size_t my_rows = me->rows;
-            for (int side = 0; side < 2; ++side) {
-                // side 0: rows above me come from tiles k-1, k-2, ...; side 1: below
-                size_t need = R, got = 0;
-                int q = side == 0 ? k - 1 : k + 1;
-                while (need > 0 && q >= 0 && q < n) {
-                    bhr_ctx *nb = ctxs[q];
-                    const size_t take = nb->rows < need ? nb->rows : need;
-                    BHR_HIP(hipStreamWaitEvent(me->stream, nb->ev[3], 0));
-                    for (int c = 0; c < 3; ++c) {
-                        const size_t nb_plane = (size_t)(nb->rows + 2 * R) * W, my_plane = (my_rows + 2 * R) * W;
-                        // neighbour's own rows live at [R, R + nb->rows)
-                        size_t src_row = side == 0 ? R + nb->rows - take : R;
-                        size_t dst_row = side == 0 ? R - got - take : R + my_rows + got;
-                        BHR_HIP(hipMemcpyPeerAsync(me->d_hblur + c * my_plane + dst_row * W, me->cfg.device,
-                                                   nb->d_hblur + c * nb_plane + src_row * W, nb->cfg.device,
-                                                   take * W * sizeof(float), me->stream));
-                    }
-                    need -= take;
-                    got += take;
-                    q += side == 0 ? -1 : 1;
-                }
-            }
-        }
-    }
-    // phase 3: V pass + combine per tile
-    for (int k = 0; k < n; ++k) {
-        BHR_TRY(use_device(ctxs[k]));
-        BHR_TRY(bhr_launch_bloom_v(ctxs[k], with_bloom));
-        BHR_HIP(hipEventRecord(ctxs[k]->ev[2], ctxs[k]->stream));
-        ctxs[k]->last_flags = (int32_t)flags;
-        ctxs[k]->timing_valid = 1;
-    }
-    // phase 3b: lens flare -- tile 0 collects every tile's glow rows and sums the frame in NumPy's order
-    if (flags & BHR_LENS_FLARE) {
-        bhr_ctx *head = ctxs[0];
-        for (int k = 0; k < n; ++k) {
-            BHR_TRY(use_device(ctxs[k]));
-            BHR_TRY(bhr_launch_flare_glow(ctxs[k], k == 0));
-            BHR_HIP(hipEventRecord(ctxs[k]->ev[3], ctxs[k]->stream));
-        }
-        BHR_TRY(use_device(head));
-        for (int k = 1; k < n; ++k) {
-            BHR_HIP(hipStreamWaitEvent(head->stream, ctxs[k]->ev[3], 0));
-            BHR_HIP(hipMemcpyPeerAsync(head->d_glow_hw + (size_t)ctxs[k]->cfg.row0 * W, head->cfg.device, ctxs[k]->d_glow_hw,
-                                       ctxs[k]->cfg.device, (size_t)ctxs[k]->rows * W * sizeof(float), head->stream));
-        }
-        BHR_TRY(bhr_launch_flare_sums(head));
-        double tot[3];
-        BHR_HIP(hipMemcpyAsync(tot, head->d_flare_sums, sizeof(tot), hipMemcpyDeviceToHost, head->stream));
-        BHR_HIP(hipStreamSynchronize(head->stream));
-        for (int k = 0; k < n; ++k) {
-            BHR_TRY(use_device(ctxs[k]));
-            BHR_TRY(bhr_launch_flare_apply(ctxs[k], tot));
-            BHR_HIP(hipEventRecord(ctxs[k]->ev[2], ctxs[k]->stream));
-        }
-    }
-    // phase 4a (BHR_GATHER_PEER): every tile pushes its final rows into the full-frame buffer on ctxs[0]'s device with
-    // hipMemcpyPeerAsync on its OWN stream -- n - 1 point-to-point xGMI links carry one tile each, concurrently
-    if (flags & BHR_GATHER_PEER) {
-        bhr_ctx *head = ctxs[0];
-        BHR_TRY(use_device(head));
-        if (!head->d_gather) BHR_TRY(dev_alloc(&head->d_gather, (size_t)H * W * 3));
-        for (int k = 0; k < n; ++k) {
-            BHR_TRY(use_device(ctxs[k]));
-            BHR_HIP(hipMemcpyPeerAsync(head->d_gather + (size_t)ctxs[k]->cfg.row0 * W * 3, head->cfg.device, ctxs[k]->d_final,
-                                       ctxs[k]->cfg.device, (size_t)ctxs[k]->rows * W * 3 * sizeof(float), ctxs[k]->stream));
-        }
-    }
-    // phase 4b: gather to the host -- every device copies into its own pinned buffer concurrently, the host
-    // then assembles the frame (a pageable destination would serialise the eight DMA streams)
-    if (out_host) {
-        for (int k = 0; k < n; ++k) {
-            BHR_TRY(use_device(ctxs[k]));
-            const size_t bytes = (size_t)ctxs[k]->rows * W * 3 * sizeof(float);
-            BHR_TRY(ensure_pinned(ctxs[k], bytes));
-            BHR_HIP(hipMemcpyAsync(ctxs[k]->h_pinned, ctxs[k]->d_final, bytes, hipMemcpyDeviceToHost, ctxs[k]->stream));
-        }
-    }
-    for (int k = 0; k < n; ++k) {
-        BHR_TRY(use_device(ctxs[k]));
-        BHR_HIP(hipStreamSynchronize(ctxs[k]->stream));
-        if (out_host)
-            memcpy(out_host + (size_t)ctxs[k]->cfg.row0 * W * 3, ctxs[k]->h_pinned, (size_t)ctxs[k]->rows * W * 3 * sizeof(float));
-    }
     return BHR_OK;
 }
 

@@ -72,6 +72,19 @@ struct BhrMarchArgs {
     unsigned long long *wave_stamps; // diagnostic (env BHR_WAVE_STAMPS): per wave s_memrealtime at start / end, steps, XCC|CU id
     int32_t n_tiles;         // 8x8 pixel tiles in the row block
     int32_t tiles_x;
+    int32_t n_list;          // launch slots of this launch (= n_tiles, or the length of a hybrid / row-band sub-list)
+};
+
+// A partial march launch: the tiles of `d_list` only.  Set by the callers that split one march into several launches --
+// bhr_launch_march_hybrid (strict list + fast list) and the pipelined row-block path (halo bands first) -- and consumed
+// by the three compilations of the launcher in march.hip.
+struct bhr_march_part {
+    const int32_t *d_list;   // device list of this launch
+    const int32_t *h_list;   // the same list on the host (the hybrid launcher partitions it further)
+    int32_t n;
+    int32_t id;              // which base list: 0 whole block, 1 halo bands, 2 the rows between them
+    int32_t active, first, last;
+    int32_t math_resolved;   // the arithmetic has been chosen by the caller (the two launches of a hybrid march)
 };
 
 // Frame slot: the buffers one frame in flight owns.  bhr_render alternates between two slots, each with its own
@@ -161,7 +174,12 @@ struct bhr_ctx {
     unsigned int *d_queue;
     unsigned long long *d_row_steps;   // ray-steps per 8-row band of the last BHR_ROW_COSTS launch
     int32_t *d_tile_order;     // march launch order of the 8x8 tiles
+    int32_t *h_tile_order;     // host copy (malloc)
     int32_t tile_order_n;
+    bhr_march_part part;       // partial launch in progress (inactive: whole block)
+    void *hybrid;              // hybrid.hip: tile classification cache
+    void *pipe;                // group.hip: streams, events and band lists of the pipelined row-block path
+    uint8_t *d_gather_u8;      // (H, W, 3) u8: quantised frame gathered from the tiles (BHR_GATHER_U8), on tile 0
     // lens flare (flare.hip)
     float *d_glow_hw;          // glow rows (rows, W); (H, W) on the context that sums the frame
     int64_t flare_glow_rows;
@@ -220,9 +238,17 @@ int32_t bhr_march_resources_strict(int32_t *vgprs, int32_t *lds, int32_t diff);
 int32_t bhr_launch_march_strict_ilp(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);   // march_strict_ilp.o
 int32_t bhr_march_resources_strict_ilp(int32_t *vgprs, int32_t *lds, int32_t diff);
 int32_t bhr_selftest_strict(bhr_ctx *ctx, unsigned long long *d_out4);
+int32_t bhr_ensure_tile_order(bhr_ctx *ctx);                                               // march.o: builds d_/h_tile_order
+int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);     // hybrid.hip
+void bhr_hybrid_free(bhr_ctx *ctx);
 int32_t bhr_bloom_prepare(bhr_ctx *ctx);
 int32_t bhr_launch_bloom_h(bhr_ctx *ctx);
 int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom);
+int32_t bhr_launch_bloom_h_rows(bhr_ctx *ctx, int32_t r0, int32_t r1);     // local rows [r0, r1)
+int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, int32_t r1, uint8_t *u8_out);
+int32_t bhr_bloom_v_tile_rows(bhr_ctx *ctx);                               // output rows per V-pass block
+void bhr_pipe_free(bhr_ctx *ctx);                                          // group.hip
+int32_t bhr_ensure_pinned(bhr_ctx *ctx, size_t bytes);                     // api.hip
 int32_t bhr_launch_flare_glow(bhr_ctx *ctx, bool whole_frame);       // flare.hip
 int32_t bhr_launch_flare_sums(bhr_ctx *ctx);
 int32_t bhr_launch_flare_apply(bhr_ctx *ctx, const double *sums);    // sums == nullptr: device-resident totals

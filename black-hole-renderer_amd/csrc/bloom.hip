@@ -19,6 +19,9 @@
 // The intermediate carries R halo rows on either side so that row-block tiles on different GPUs can
 // exchange them (bhr_group_render).  Summation order differs from the reference's tap order
 // (-R .. R) only by f32 rounding (tests: 2e-6 against the CPU restatement in the tests).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "bhr_internal.h"
 
 namespace {
@@ -93,12 +96,12 @@ __device__ __forceinline__ void conv4(const float *__restrict__ win, int M, cons
 // grid (ceil(W / 1024), rows).  hblur row index = local row + R.
 __global__ __launch_bounds__(256) void bloom_h_kernel(const float *__restrict__ disk, float *__restrict__ hblur,
                                                       const float *__restrict__ wext,
-                                                      const float *__restrict__ wsum_h, int W, int rows, int R) {
+                                                      const float *__restrict__ wsum_h, int W, int rows, int R, int row_begin) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int R4 = (R + 3) & ~3;
     const int span = HB_PIX + 2 * R4 + 4;          // per-channel window, multiple of 4
     const int x0 = blockIdx.x * HB_PIX;
-    const int row = blockIdx.y;
+    const int row = blockIdx.y + row_begin;        // the launch covers local rows [row_begin, row_begin + gridDim.y)
     const int tid = threadIdx.x;
     const int xstride = 2 * R4 + 8;
 
@@ -137,7 +140,8 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
                                                       float *__restrict__ final_out, const float *__restrict__ wext,
                                                       const float *__restrict__ wsum_v, int W, int H, int row0,
                                                       int rows, int R, int S, int with_bloom,
-                                                      unsigned long long *__restrict__ zero_cell) {
+                                                      unsigned long long *__restrict__ zero_cell, int row_begin, int row_end,
+                                                      uint8_t *__restrict__ u8_out) {
     // housekeeping folded into the frame's last kernel: clear the ray-step counter cell of the NEXT timed frame,
     // which saves a fill dispatch (and its barrier) in front of every march
     if (zero_cell && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < BHR_STEP_LANES)
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
     const int lane_g = threadIdx.x >> 5;           // 0..7
     const int x = blockIdx.x * VB_COLS + col;
     constexpr int VB_ROWS = 32 * G;
-    const int y0 = blockIdx.y * VB_ROWS;           // local row of the first output of the tile
+    const int y0 = row_begin + blockIdx.y * VB_ROWS;   // local row of the first output of the tile; the launch covers [row_begin, row_end)
     const int xstride = 2 * R4 + 8;
     const int tile_rows = VB_ROWS + 2 * R4 + 4;
     const int M = (2 * R4) / 4 + 1;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int yl = y0 + 4 * grp + k;
-            if (yl >= rows) continue;
+            if (yl >= row_end) continue;
             const int yg = yl + row0;
             float b0 = 0, b1 = 0, b2 = 0;
             if (with_bloom) {
@@ -207,24 +211,211 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
             blur_out[o + 1] = b1;
             blur_out[o + 2] = b2;
             // render.py:3912 / 3918: clip(img + disk [+ blur], 0, 1)
-            final_out[o + 0] = fminf(fmaxf(bg[o + 0] + disk[o + 0] + b0, 0.0f), 1.0f);
-            final_out[o + 1] = fminf(fmaxf(bg[o + 1] + disk[o + 1] + b1, 0.0f), 1.0f);
-            final_out[o + 2] = fminf(fmaxf(bg[o + 2] + disk[o + 2] + b2, 0.0f), 1.0f);
+            const float f0 = fminf(fmaxf(bg[o + 0] + disk[o + 0] + b0, 0.0f), 1.0f);
+            const float f1 = fminf(fmaxf(bg[o + 1] + disk[o + 1] + b1, 0.0f), 1.0f);
+            const float f2 = fminf(fmaxf(bg[o + 2] + disk[o + 2] + b2, 0.0f), 1.0f);
+            final_out[o + 0] = f0;
+            final_out[o + 1] = f1;
+            final_out[o + 2] = f2;
+            if (u8_out) {   // save_image's quantisation fused in (render.py:423): the row-block gather ships these bytes
+                u8_out[o + 0] = (uint8_t)(int)(f0 * 255.0f);
+                u8_out[o + 1] = (uint8_t)(int)(f1 * 255.0f);
+                u8_out[o + 2] = (uint8_t)(int)(f2 * 255.0f);
+            }
         }
     }
 }
 
-// measured: 256-row tiles win at 8k (R = 153: 2.0 -> 1.74 ms) and lose at 4k (R = 76: one block fewer per CU)
-int v_groups(int R, int rows) {
-    if (const char *e = getenv("BHR_BLOOM_VG")) { int g = atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8) return g; }
-    if (R < 64) return 1;   // fhd and below: 32-row tiles -- the pass is short of waves (one round), not of FMAs
-    return (R >= 128 && rows > 128) ? 8 : 4;
+// ---- round 3 variants: every tap block's seven weights are fetched ONCE for all the thread's output groups ------------
+// conv4 above serves one group of 4 outputs per call, so a thread with G groups walks the weight table G times and
+// every 16 FMAs wait for their own scalar load.  conv4g keeps NG accumulator groups live and feeds all of them from one
+// fetch: 16 NG FMAs per scalar load, NG independent dependency chains per lane.
+template <int NG>
+__device__ __forceinline__ void conv4g(const float *__restrict__ win, int gstride, int M, const float *__restrict__ wx,
+                                       float (&acc)[NG][4]) {
+#pragma unroll 2
+    for (int m = 0; m < M; ++m) {
+        const float *__restrict__ wp = wx + 4 * m;
+        float w[7];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) w[t] = wp[t];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float4 v = *reinterpret_cast<const float4 *>(win + g * gstride + 4 * m);
+            acc[g][0] = fmaf(v.x, w[3], fmaf(v.y, w[4], fmaf(v.z, w[5], fmaf(v.w, w[6], acc[g][0]))));
+            acc[g][1] = fmaf(v.x, w[2], fmaf(v.y, w[3], fmaf(v.z, w[4], fmaf(v.w, w[5], acc[g][1]))));
+            acc[g][2] = fmaf(v.x, w[1], fmaf(v.y, w[2], fmaf(v.z, w[3], fmaf(v.w, w[4], acc[g][2]))));
+            acc[g][3] = fmaf(v.x, w[0], fmaf(v.y, w[1], fmaf(v.z, w[2], fmaf(v.w, w[3], acc[g][3]))));
+        }
+    }
 }
-int v_stride(int R, int groups) {   // LDS column stride: >= tile rows, multiple of 4 with an odd quotient (bank spread)
+
+// H pass, NG groups per thread 1024 pixels apart: a block covers 1024 NG pixels of one row.
+template <int NG>
+__global__ __launch_bounds__(256) void bloom_h2_kernel(const float *__restrict__ disk, float *__restrict__ hblur,
+                                                       const float *__restrict__ wext, const float *__restrict__ wsum_h,
+                                                       int W, int rows, int R, int row_begin) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PIX = HB_PIX * NG;
     const int R4 = (R + 3) & ~3;
-    int s = 32 * groups + 2 * R4 + 4;
+    const int span = PIX + 2 * R4 + 4;
+    const int x0 = blockIdx.x * PIX;
+    const int row = blockIdx.y + row_begin;
+    const int tid = threadIdx.x;
+    const int xstride = 2 * R4 + 8;
+    const float *src = disk + (size_t)row * W * 3;
+    // stage pixels [x0 - R4, x0 + PIX + R4 + 4): each thread moves whole pixels (3 consecutive floats), no division
+    for (int p = tid; p < span; p += 256) {
+        const int x = x0 - R4 + p;
+        float a = 0.0f, b = 0.0f, c = 0.0f;
+        if (x >= 0 && x < W) { a = src[(size_t)x * 3]; b = src[(size_t)x * 3 + 1]; c = src[(size_t)x * 3 + 2]; }
+        lds[p] = a;
+        lds[span + p] = b;
+        lds[2 * span + p] = c;
+    }
+    __syncthreads();
+    const int M = (2 * R4) / 4 + 1;
+    const size_t plane = (size_t)(rows + 2 * R) * W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float acc[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g][0] = acc[g][1] = acc[g][2] = acc[g][3] = 0.0f;
+        conv4g<NG>(lds + c * span + 4 * tid, HB_PIX, M, wext + c * xstride, acc);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int x = x0 + g * HB_PIX + 4 * tid;
+            if (x >= W) continue;
+            float *dst = hblur + c * plane + (size_t)(row + R) * W + x;
+            const float *ws = wsum_h + c * W + x;
+            if (x + 3 < W && (W & 3) == 0) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(acc[g][0] / ws[0], acc[g][1] / ws[1], acc[g][2] / ws[2], acc[g][3] / ws[3]);
+            } else {
+                for (int k = 0; k < 4 && x + k < W; ++k) dst[k] = acc[g][k] / ws[k];
+            }
+        }
+    }
+}
+
+// V pass, COLS columns x (256 / COLS) row lanes x G groups x 4 rows per block.  COLS = 16 halves the LDS tile of the
+// 32-column kernel (the 2 R halo rows dominate it: 73 KB at 8k, two blocks per CU), so four blocks fit a CU.
+template <int COLS, int G>
+__global__ __launch_bounds__(256) void bloom_v2_kernel(const float *__restrict__ hblur, const float *__restrict__ bg,
+                                                       const float *__restrict__ disk, float *__restrict__ blur_out,
+                                                       float *__restrict__ final_out, const float *__restrict__ wext,
+                                                       const float *__restrict__ wsum_v, int W, int H, int row0, int rows,
+                                                       int R, int S, int with_bloom, unsigned long long *__restrict__ zero_cell,
+                                                       int row_begin, int row_end, uint8_t *__restrict__ u8_out) {
+    if (zero_cell && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < BHR_STEP_LANES)
+        zero_cell[(size_t)threadIdx.x * BHR_STEP_STRIDE] = 0ull;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [COLS][S], column-major tile
+    constexpr int LG = 256 / COLS;                 // row lanes
+    constexpr int VROWS = LG * 4 * G;              // output rows per block
+    const int R4 = (R + 3) & ~3;
+    const int col = threadIdx.x % COLS;
+    const int lane_g = threadIdx.x / COLS;
+    const int x = blockIdx.x * COLS + col;
+    const int y0 = row_begin + blockIdx.y * VROWS;
+    const int xstride = 2 * R4 + 8;
+    const int tile_rows = VROWS + 2 * R4 + 4;
+    const int M = (2 * R4) / 4 + 1;
+
+    float res[3][G][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int g = 0; g < G; ++g) res[c][g][0] = res[c][g][1] = res[c][g][2] = res[c][g][3] = 0.0f;
+
+    if (with_bloom) {
+        const size_t plane = (size_t)(rows + 2 * R) * W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            __syncthreads();
+            for (int k = threadIdx.x; k < tile_rows * COLS; k += 256) {
+                const int r = k / COLS, cc = k % COLS;
+                const int yl = y0 - R4 + r, yg = yl + row0, xx = blockIdx.x * COLS + cc;
+                float v = 0.0f;
+                if (yg >= 0 && yg < H && yl >= -R && yl < rows + R && xx < W) v = hblur[c * plane + (size_t)(yl + R) * W + xx];
+                lds[cc * S + r] = v;
+            }
+            __syncthreads();
+            // group g of this lane = rows 4 (lane_g + LG g) .. + 3 of the tile
+            conv4g<G>(lds + col * S + 4 * lane_g, 4 * LG, M, wext + c * xstride, res[c]);
+        }
+    }
+    if (x >= W) return;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int grp = lane_g + LG * g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yl = y0 + 4 * grp + k;
+            if (yl >= row_end) continue;
+            const int yg = yl + row0;
+            float b0 = 0, b1 = 0, b2 = 0;
+            if (with_bloom) {
+                b0 = res[0][g][k] / wsum_v[yg];
+                b1 = res[1][g][k] / wsum_v[H + yg];
+                b2 = res[2][g][k] / wsum_v[2 * H + yg];
+            }
+            const size_t o = ((size_t)yl * W + x) * 3;
+            blur_out[o + 0] = b0;
+            blur_out[o + 1] = b1;
+            blur_out[o + 2] = b2;
+            const float f0 = fminf(fmaxf(bg[o + 0] + disk[o + 0] + b0, 0.0f), 1.0f);
+            const float f1 = fminf(fmaxf(bg[o + 1] + disk[o + 1] + b1, 0.0f), 1.0f);
+            const float f2 = fminf(fmaxf(bg[o + 2] + disk[o + 2] + b2, 0.0f), 1.0f);
+            final_out[o + 0] = f0;
+            final_out[o + 1] = f1;
+            final_out[o + 2] = f2;
+            if (u8_out) {
+                u8_out[o + 0] = (uint8_t)(int)(f0 * 255.0f);
+                u8_out[o + 1] = (uint8_t)(int)(f1 * 255.0f);
+                u8_out[o + 2] = (uint8_t)(int)(f2 * 255.0f);
+            }
+        }
+    }
+}
+
+// V-pass geometry of this context: columns per block, row groups per thread (rows per block = 256 / cols x 4 x groups).
+// BHR_BLOOM_V="<cols>x<groups>" overrides ("32x0": the round-2 kernel with its own table below); BHR_BLOOM_H=<NG>.
+struct VGeom { int cols, groups, v2; };
+// Round-2 table of the 32-column kernel (v2 = 0): G = 1 (32 rows) up to fhd, 4 at 4k, 8 (256 rows) at 8k.
+VGeom v_geometry(int R, int rows) {
+    VGeom g{32, 1, 0};
+    if (R >= 64) g.groups = (R >= 128 && rows > 128) ? 8 : 4;
+    if (const char *e = getenv("BHR_BLOOM_VG")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) g.groups = v; }
+    if (const char *e = getenv("BHR_BLOOM_V")) {
+        int c = 0, k = 0;
+        if (sscanf(e, "%dx%d", &c, &k) == 2 && (c == 16 || c == 32) && (k == 0 || k == 1 || k == 2 || k == 4 || k == 8)) {
+            if (k != 0) { g.cols = c; g.groups = k; g.v2 = 1; }
+        }
+    }
+    return g;
+}
+int v_rows_per_block(const VGeom &g) { return 256 / g.cols * 4 * g.groups; }
+int v_stride(int R, const VGeom &g) {   // LDS column stride: >= tile rows, multiple of 4 with an odd quotient (bank spread)
+    const int R4 = (R + 3) & ~3;
+    int s = v_rows_per_block(g) + 2 * R4 + 4;
     if (((s >> 2) & 1) == 0) s += 4;
     return s;
+}
+int h_groups() {
+    if (const char *e = getenv("BHR_BLOOM_H")) { int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) return v; }
+    return 0;                             // 0: the round-2 kernel
+}
+
+// kernels that need more than 48 KB of dynamic LDS are told so once
+int32_t allow_lds(const void *fn, size_t bytes) {
+    static const void *done[64];
+    static size_t done_bytes[64];
+    static int n_done = 0;
+    if (bytes <= 48 * 1024) return BHR_OK;
+    for (int k = 0; k < n_done; ++k)
+        if (done[k] == fn && done_bytes[k] >= bytes) return BHR_OK;
+    BHR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (n_done < 64) { done[n_done] = fn; done_bytes[n_done++] = bytes; }
+    return BHR_OK;
 }
 
 }  // namespace
@@ -244,47 +435,70 @@ int32_t bhr_bloom_prepare(bhr_ctx *ctx) {
     hipLaunchKernelGGL(bloom_wsum_kernel, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wtab, ctx->d_wsum_h, R, W);
     hipLaunchKernelGGL(bloom_wsum_kernel, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wtab, ctx->d_wsum_v, R, H);
     BHR_HIP(hipGetLastError());
-    const int G = v_groups(R, ctx->rows);
-    const size_t v_lds = (size_t)VB_COLS * v_stride(R, G) * sizeof(float);
-    if (v_lds > 48 * 1024)
-        BHR_HIP(hipFuncSetAttribute(G == 8 ? (const void *)bloom_v_kernel<8> : G == 4 ? (const void *)bloom_v_kernel<4> : G == 2 ? (const void *)bloom_v_kernel<2> : (const void *)bloom_v_kernel<1>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)v_lds));
     ctx->bloom_ready = 1;
     return BHR_OK;
 }
 
-int32_t bhr_launch_bloom_h(bhr_ctx *ctx) {
+// H pass over the local rows [r0, r1) of the context (the pipelined row-block path blurs its halo bands first)
+int32_t bhr_launch_bloom_h_rows(bhr_ctx *ctx, int32_t r0, int32_t r1) {
     const int W = ctx->cfg.width, R = ctx->bloom_R;
     int32_t rc = bhr_bloom_prepare(ctx);
     if (rc) return rc;
+    if (r0 < 0 || r1 > ctx->rows || r0 > r1) return bhr_fail(BHR_ERR_INVALID, "bloom H: rows [%d,%d) of %d", r0, r1, ctx->rows);
+    if (r0 == r1) return BHR_OK;
     const int R4 = (R + 3) & ~3;
-    dim3 grid((W + HB_PIX - 1) / HB_PIX, ctx->rows), block(256);
-    size_t lds = (size_t)3 * (HB_PIX + 2 * R4 + 4) * sizeof(float);
-    hipLaunchKernelGGL(bloom_h_kernel, grid, block, lds, ctx->stream, ctx->d_disk, ctx->d_hblur, ctx->d_wext,
-                       ctx->d_wsum_h, W, ctx->rows, R);
+    const int ng = h_groups();
+    const int pix = HB_PIX * (ng ? ng : 1);
+    dim3 grid((W + pix - 1) / pix, r1 - r0), block(256);
+    const size_t lds = (size_t)3 * (pix + 2 * R4 + 4) * sizeof(float);
+#define BHR_H_ARGS grid, block, lds, ctx->stream, ctx->d_disk, ctx->d_hblur, ctx->d_wext, ctx->d_wsum_h, W, ctx->rows, R, r0
+    if (ng == 0) { hipLaunchKernelGGL(bloom_h_kernel, BHR_H_ARGS); }
+    else if (ng == 1) { hipLaunchKernelGGL(bloom_h2_kernel<1>, BHR_H_ARGS); }
+    else if (ng == 2) { hipLaunchKernelGGL(bloom_h2_kernel<2>, BHR_H_ARGS); }
+    else { BHR_TRY(allow_lds((const void *)bloom_h2_kernel<4>, lds)); hipLaunchKernelGGL(bloom_h2_kernel<4>, BHR_H_ARGS); }
+#undef BHR_H_ARGS
     BHR_HIP(hipGetLastError());
     return BHR_OK;
 }
 
-int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom) {
+int32_t bhr_launch_bloom_h(bhr_ctx *ctx) { return bhr_launch_bloom_h_rows(ctx, 0, ctx->rows); }
+
+int32_t bhr_bloom_v_tile_rows(bhr_ctx *ctx) { return v_rows_per_block(v_geometry(ctx->bloom_R, ctx->rows)); }
+
+// V pass + combine over the local rows [r0, r1); u8_out != nullptr: also the quantised final rows ((rows, W, 3) u8 base)
+int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, int32_t r1, uint8_t *u8_out) {
     const int W = ctx->cfg.width, H = ctx->cfg.height, R = ctx->bloom_R;
     int32_t rc = bhr_bloom_prepare(ctx);
     if (rc) return rc;
-    const int G = v_groups(R, ctx->rows), S = v_stride(R, G), vb_rows = 32 * G;
-    dim3 grid((W + VB_COLS - 1) / VB_COLS, (ctx->rows + vb_rows - 1) / vb_rows), block(256);
-    size_t lds = with_bloom ? (size_t)VB_COLS * S * sizeof(float) : 0;
-    if (G == 8)
-        hipLaunchKernelGGL(bloom_v_kernel<8>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
-                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom, ctx->v_zero_cell);
-    else if (G == 4)
-        hipLaunchKernelGGL(bloom_v_kernel<4>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
-                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom, ctx->v_zero_cell);
-    else if (G == 1)
-        hipLaunchKernelGGL(bloom_v_kernel<1>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
-                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom, ctx->v_zero_cell);
-    else
-        hipLaunchKernelGGL(bloom_v_kernel<2>, grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur,
-                           ctx->d_final, ctx->d_wext, ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom, ctx->v_zero_cell);
+    if (r0 < 0 || r1 > ctx->rows || r0 > r1) return bhr_fail(BHR_ERR_INVALID, "bloom V: rows [%d,%d) of %d", r0, r1, ctx->rows);
+    if (r0 == r1) return BHR_OK;
+    const VGeom g = v_geometry(R, ctx->rows);
+    const int S = v_stride(R, g), vb_rows = v_rows_per_block(g);
+    dim3 grid((W + g.cols - 1) / g.cols, (r1 - r0 + vb_rows - 1) / vb_rows), block(256);
+    const size_t lds = with_bloom ? (size_t)g.cols * S * sizeof(float) : 0;
+#define BHR_V_ARGS grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_wext, \
+                   ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom, ctx->v_zero_cell, r0, r1, u8_out
+#define BHR_V_LAUNCH(KERNEL) do { BHR_TRY(allow_lds((const void *)KERNEL, lds)); hipLaunchKernelGGL(KERNEL, BHR_V_ARGS); } while (0)
+    if (!g.v2) {
+        if (g.groups == 8) BHR_V_LAUNCH(bloom_v_kernel<8>);
+        else if (g.groups == 4) BHR_V_LAUNCH(bloom_v_kernel<4>);
+        else if (g.groups == 1) BHR_V_LAUNCH(bloom_v_kernel<1>);
+        else BHR_V_LAUNCH(bloom_v_kernel<2>);
+    } else if (g.cols == 32) {
+        if (g.groups == 8) BHR_V_LAUNCH((bloom_v2_kernel<32, 8>));
+        else if (g.groups == 4) BHR_V_LAUNCH((bloom_v2_kernel<32, 4>));
+        else if (g.groups == 1) BHR_V_LAUNCH((bloom_v2_kernel<32, 1>));
+        else BHR_V_LAUNCH((bloom_v2_kernel<32, 2>));
+    } else {
+        if (g.groups == 8) BHR_V_LAUNCH((bloom_v2_kernel<16, 8>));
+        else if (g.groups == 4) BHR_V_LAUNCH((bloom_v2_kernel<16, 4>));
+        else if (g.groups == 1) BHR_V_LAUNCH((bloom_v2_kernel<16, 1>));
+        else BHR_V_LAUNCH((bloom_v2_kernel<16, 2>));
+    }
+#undef BHR_V_LAUNCH
+#undef BHR_V_ARGS
     BHR_HIP(hipGetLastError());
     return BHR_OK;
 }
+
+int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom) { return bhr_launch_bloom_v_rows(ctx, with_bloom, 0, ctx->rows, nullptr); }

@@ -1,0 +1,223 @@
+// hybrid.hip -- math_mode BHR_MATH_HYBRID: the strict march where the geodesic is unstable, the fast march elsewhere.
+//
+// Why a static, per-tile choice is enough.  The reference's equation of motion (render.py:2518-2524) is the
+// Schwarzschild null geodesic in Binet form; it is integrable, and the only rays that amplify rounding are those whose
+// impact parameter b = |pos x dir| (= sqrt(L2) of render.py:2828, conserved) lies next to the critical value
+// b_c = (3 sqrt 3 / 2) r_s of the photon sphere: they wind around r = 1.5 r_s and their deflection grows like
+// -ln|b / b_c - 1|, so an error eps made anywhere on the inbound leg leaves as eps b / |b - b_c|.  Everything else --
+// direct disk hits, weakly bent sky rays, rays that fall straight in -- carries the ~1e-7 per-step rounding of the fast
+// arithmetic through unamplified.  A ray is unstable for its whole life or not at all (b is fixed when it is
+// launched), hence no switching in flight: an 8x8-pixel tile whose rays have b inside [b_c - lo, b_c + hi] is marched
+// by the STRICT kernel (bit-identical paths, as math_mode 1), every other tile by the FAST kernel.  The two kernels are
+// the ones the other two modes launch; hybrid is host code: the classification (b at the tile corners in binary64
+// from the camera uniforms, padded by one tile's span), a stable partition of the context's longest-first tile order
+// into two device lists, and two launches bracketed as one march.  The lists are cached per frame slot and reused
+// while the view's geometry (|cam|, cam . {forward, right, up}, pixel pitch) is unchanged -- an orbit at constant
+// radius keeps them for the whole video.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "bhr_internal.h"
+
+namespace {
+
+constexpr double B_CRIT = 2.598076211353316;   // 3 sqrt(3) / 2 r_s, r_s = 1
+
+constexpr int HYBRID_LISTS = 3;   // base lists a march can be launched over: whole block, halo bands, the rest (bhr_march_part.id)
+
+struct SlotLists {
+    int32_t *d_list;       // the base list partitioned: strict tiles first (launch order kept), then the fast ones
+    int32_t *h_pinned;
+    hipEvent_t copied;     // the last upload from h_pinned
+    double key[8];
+    int32_t n_strict, base_n, valid, pending;
+};
+
+struct Hybrid {
+    SlotLists slot[BHR_MAX_FRAME_SLOTS][HYBRID_LISTS];
+    // last classification on the host
+    std::vector<uint8_t> strict;   // per tile of the row block: marched strict
+    double key[8];
+    int32_t n_strict, valid;
+    double lo, hi;                 // band below / above b_c (BHR_HYBRID_BAND="lo,hi")
+};
+
+void view_key(const bhr_camera *cam, double lo, double hi, double key[8]) {
+    double p[3], r2 = 0, pf = 0, pr = 0, pu = 0;
+    for (int k = 0; k < 3; ++k) {
+        p[k] = cam->pos[k];
+        r2 += p[k] * p[k];
+        pf += p[k] * (double)cam->forward[k];
+        pr += p[k] * (double)cam->right[k];
+        pu += p[k] * (double)cam->up[k];
+    }
+    key[0] = sqrt(r2); key[1] = pf; key[2] = pr; key[3] = pu;
+    key[4] = cam->pixel_width; key[5] = cam->pixel_height; key[6] = lo; key[7] = hi;
+}
+
+// the classification only depends on the view through the key; geometry within 1e-5 (absolute, in r_s) of the cached
+// one moves b by less than the 1e-3 the band is padded with
+bool same_view(const double a[8], const double b[8]) {
+    for (int k = 0; k < 4; ++k)
+        if (fabs(a[k] - b[k]) > 1e-5) return false;
+    for (int k = 4; k < 8; ++k)
+        if (a[k] != b[k]) return false;
+    return true;
+}
+
+// strict[t] = 1 for the tiles of this row block whose rays may have b in [b_c - lo, b_c + hi]
+void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, std::vector<uint8_t> &strict) {
+    const int W = ctx->cfg.width, H = ctx->cfg.height, row0 = ctx->cfg.row0, rows = ctx->rows;
+    const int tiles_x = (W + 7) / 8, tiles_y = (rows + 7) / 8;
+    double cp[3], cr[3], cu[3], cf[3], tl[3];
+    for (int k = 0; k < 3; ++k) { cp[k] = cam->pos[k]; cr[k] = cam->right[k]; cu[k] = cam->up[k]; cf[k] = cam->forward[k]; }
+    const double pw = cam->pixel_width, ph = cam->pixel_height;
+    const double half_w = pw * W / 2, half_h = ph * H / 2;
+    for (int k = 0; k < 3; ++k) tl[k] = cp[k] + cf[k] - half_w * cr[k] + half_h * cu[k];   // render.py:2811-2816
+    const double r0sq = cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2];
+    // b and the radial sense at the tile-boundary grid: x = 8 gx - 0.5, y = row0 + 8 gy - 0.5 in pixel-centre units
+    const int gx_n = tiles_x + 1, gy_n = tiles_y + 1;
+    std::vector<float> bgrid((size_t)gx_n * gy_n);
+    std::vector<uint8_t> outgoing((size_t)gx_n * gy_n);
+    for (int gy = 0; gy < gy_n; ++gy) {
+        const double y = (double)row0 + (double)(gy * 8 < rows ? gy * 8 : rows) - 0.5;
+        for (int gx = 0; gx < gx_n; ++gx) {
+            const double x = (double)(gx * 8 < W ? gx * 8 : W) - 0.5;
+            double d[3], dn = 0, pd = 0;
+            for (int k = 0; k < 3; ++k) {
+                d[k] = tl[k] + (x + 0.5) * pw * cr[k] - (y + 0.5) * ph * cu[k] - cp[k];
+                dn += d[k] * d[k];
+                pd += cp[k] * d[k];
+            }
+            pd /= sqrt(dn);
+            const double b2 = r0sq - pd * pd;
+            bgrid[(size_t)gy * gx_n + gx] = (float)sqrt(b2 > 0 ? b2 : 0);
+            outgoing[(size_t)gy * gx_n + gx] = pd > 0;
+        }
+    }
+    const bool far_cam = r0sq > 9.0;     // outside 3 r_s an outgoing ray never comes near the photon sphere
+    strict.assign((size_t)tiles_x * tiles_y, 0);
+    for (int ty = 0; ty < tiles_y; ++ty)
+        for (int tx = 0; tx < tiles_x; ++tx) {
+            const size_t g = (size_t)ty * gx_n + tx;
+            const float c[4] = {bgrid[g], bgrid[g + 1], bgrid[g + gx_n], bgrid[g + gx_n + 1]};
+            float bmin = c[0], bmax = c[0];
+            for (int k = 1; k < 4; ++k) { bmin = c[k] < bmin ? c[k] : bmin; bmax = c[k] > bmax ? c[k] : bmax; }
+            if (far_cam && outgoing[g] && outgoing[g + 1] && outgoing[g + gx_n] && outgoing[g + gx_n + 1]) continue;
+            // b is the distance from the hole's image in a convex sense: its maximum over the tile is at a corner, its
+            // minimum may lie on an edge -- pad by the tile's own span
+            const double pad = (double)(bmax - bmin) + 1e-3;
+            if (bmax + pad >= B_CRIT - lo && bmin - pad <= B_CRIT + hi) strict[(size_t)ty * tiles_x + tx] = 1;
+        }
+}
+
+}  // namespace
+
+void bhr_hybrid_free(bhr_ctx *ctx) {
+    Hybrid *h = (Hybrid *)ctx->hybrid;
+    if (!h) return;
+    for (auto &row : h->slot)
+        for (auto &s : row) {
+            if (s.d_list) (void)hipFree(s.d_list);
+            if (s.h_pinned) (void)hipHostFree(s.h_pinned);
+            if (s.copied) (void)hipEventDestroy(s.copied);
+        }
+    delete h;
+    ctx->hybrid = nullptr;
+}
+
+extern "C" int32_t bhr_hybrid_info(bhr_ctx *ctx, int32_t out_tiles[2], double out_band[2]) {
+    if (!ctx || !out_tiles || !out_band) return bhr_fail(BHR_ERR_INVALID, "bhr_hybrid_info: bad argument");
+    Hybrid *h = (Hybrid *)ctx->hybrid;
+    if (!h || !h->valid) return bhr_fail(BHR_ERR_STATE, "bhr_hybrid_info: no hybrid march has run on this context");
+    out_tiles[0] = h->n_strict;
+    out_tiles[1] = (int32_t)h->strict.size();
+    out_band[0] = h->lo;
+    out_band[1] = h->hi;
+    return BHR_OK;
+}
+
+int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
+    BHR_TRY(bhr_ensure_tile_order(ctx));
+    Hybrid *h = (Hybrid *)ctx->hybrid;
+    if (!h) {
+        h = new Hybrid();
+        memset(h->slot, 0, sizeof(h->slot));
+        h->valid = 0;
+        h->n_strict = 0;
+        // band around b_c, in r_s: measured on the fixtures and the fhd / 4k / e2e frames (tools/hybrid_sweep.py)
+        h->lo = 0.12;
+        h->hi = 0.30;
+        if (const char *e = getenv("BHR_HYBRID_BAND")) {
+            double a = 0, b = 0;
+            if (sscanf(e, "%lf,%lf", &a, &b) == 2 && a >= 0 && b >= 0) { h->lo = a; h->hi = b; }
+        }
+        ctx->hybrid = h;
+    }
+    // the list to split: the whole row block, or the sub-list of a pipelined launch (halo bands / the rest)
+    const bhr_march_part base = ctx->part;
+    const int32_t *base_list = base.active ? base.h_list : ctx->h_tile_order;
+    const int base_n = base.active ? base.n : ctx->tile_order_n;
+    const int id = base.active ? base.id : 0;
+    if (id < 0 || id >= HYBRID_LISTS || !base_list) return bhr_fail(BHR_ERR_INVALID, "hybrid march: bad base list %d", id);
+    double key[8];
+    view_key(cam, h->lo, h->hi, key);
+    if (!h->valid || !same_view(h->key, key)) {
+        classify(ctx, cam, h->lo, h->hi, h->strict);
+        int n = 0;
+        for (int k = 0; k < ctx->tile_order_n; ++k) n += h->strict[(size_t)k];
+        h->n_strict = n;
+        memcpy(h->key, key, sizeof(key));
+        h->valid = 1;
+    }
+    SlotLists &s = h->slot[ctx->active_slot >= 0 && ctx->active_slot < BHR_MAX_FRAME_SLOTS ? ctx->active_slot : 0][id];
+    if (!s.d_list) {
+        BHR_HIP(hipMalloc((void **)&s.d_list, (size_t)ctx->tile_order_n * sizeof(int32_t)));
+        BHR_HIP(hipHostMalloc((void **)&s.h_pinned, (size_t)ctx->tile_order_n * sizeof(int32_t), hipHostMallocDefault));
+        BHR_HIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+    }
+    if (!s.valid || s.base_n != base_n || memcmp(s.key, h->key, sizeof(s.key)) != 0) {
+        // the slot's stream is in order: the upload lands behind the slot's previous march; the pinned source is free
+        // once its previous upload has completed
+        if (s.pending) BHR_HIP(hipEventSynchronize(s.copied));
+        int n = 0;                                   // stable partition: the launch order is kept inside both halves
+        for (int k = 0; k < base_n; ++k)
+            if (h->strict[(size_t)base_list[k]]) s.h_pinned[n++] = base_list[k];
+        s.n_strict = n;
+        for (int k = 0; k < base_n; ++k)
+            if (!h->strict[(size_t)base_list[k]]) s.h_pinned[n++] = base_list[k];
+        BHR_HIP(hipMemcpyAsync(s.d_list, s.h_pinned, (size_t)base_n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        BHR_HIP(hipEventRecord(s.copied, ctx->stream));
+        s.pending = 1;
+        memcpy(s.key, h->key, sizeof(s.key));
+        s.base_n = base_n;
+        s.valid = 1;
+    }
+    const uint32_t f = flags & ~(BHR_FORCE_FAST | BHR_FORCE_STRICT | BHR_FORCE_HYBRID);
+    // longest rays first: the strict tiles are the ones around the photon ring
+    bhr_march_part p;
+    p.d_list = s.d_list;
+    p.h_list = nullptr;
+    p.n = s.n_strict;
+    p.id = id;
+    p.active = 1;
+    p.math_resolved = 1;
+    p.first = base.active ? base.first : 1;
+    p.last = 0;
+    ctx->part = p;
+    int32_t rc = bhr_launch_march_strict(ctx, cam, f);
+    if (rc == BHR_OK) {
+        p.d_list = s.d_list + s.n_strict;
+        p.n = base_n - s.n_strict;
+        p.first = 0;
+        p.last = base.active ? base.last : 1;
+        ctx->part = p;
+        rc = bhr_launch_march(ctx, cam, f);
+    }
+    ctx->part = base;
+    return rc;
+}

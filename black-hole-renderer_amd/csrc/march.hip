@@ -908,7 +908,8 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
     // one 8x8 tile per wave; `slot` is its position in the launch order
     // tiles are handed out longest first (tile_order: by distance from the image of the hole, where rays take the
     // most steps), so that the launch does not end on a few late, long waves
-    const int tile = (a.tile_order && slot < a.n_tiles) ? a.tile_order[slot] : slot;
+    // n_list = launch slots of THIS launch: all tiles of the row block, or the sub-list a hybrid launch hands this kernel
+    const int tile = slot < a.n_list ? (a.tile_order ? a.tile_order[slot] : slot) : a.n_tiles;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int i = tx * 8 + (lane & 7);
     const int j = ty * 8 + (lane >> 3);
@@ -980,7 +981,7 @@ __device__ __forceinline__ void march_tiles_of_wave(const BhrMarchArgs &a) {
 #pragma unroll 1
     for (int t = 0; t < BHR_TPW; ++t) {
         const int slot = wave + t * n_waves;
-        if (slot < a.n_tiles) march_tile_body<DIFF, 0>(a, slot);
+        if (slot < a.n_list) march_tile_body<DIFF, 0>(a, slot);
     }
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void march_tile_plain_ilp(BhrMarchArgs a) { march_tiles_of_wave<false>(a); }
@@ -1119,13 +1120,23 @@ static int32_t ensure_tile_order(bhr_ctx *ctx, int tiles_x, int n_tiles) {
     }
     std::stable_sort(key.begin(), key.end(),
                      [](const std::pair<float, int> &l, const std::pair<float, int> &r) { return l.first < r.first; });
-    std::vector<int32_t> order((size_t)n_tiles);
-    for (int t = 0; t < n_tiles; ++t) order[(size_t)t] = key[(size_t)t].second;
+    // the host keeps a copy: hybrid and pipelined launches partition this order into sub-lists (api.hip, hybrid.hip)
+    free(ctx->h_tile_order);
+    ctx->h_tile_order = (int32_t *)malloc((size_t)n_tiles * sizeof(int32_t));
+    if (!ctx->h_tile_order) return bhr_fail(BHR_ERR_NOMEM, "tile order: out of host memory");
+    for (int t = 0; t < n_tiles; ++t) ctx->h_tile_order[t] = key[(size_t)t].second;
     BHR_HIP(hipMalloc((void **)&ctx->d_tile_order, (size_t)n_tiles * sizeof(int32_t)));
-    BHR_HIP(hipMemcpy(ctx->d_tile_order, order.data(), (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
+    BHR_HIP(hipMemcpy(ctx->d_tile_order, ctx->h_tile_order, (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
     ctx->tile_order_n = n_tiles;
     return BHR_OK;
 }
+
+#if !BHR_MARCH_STRICT
+int32_t bhr_ensure_tile_order(bhr_ctx *ctx) {
+    const int tiles_x = (ctx->cfg.width + 7) / 8;
+    return ensure_tile_order(ctx, tiles_x, tiles_x * ((ctx->rows + 7) / 8));
+}
+#endif
 
 int32_t BHR_MARCH_RESOURCES(int32_t *vgprs, int32_t *lds, int32_t diff) {
     hipFuncAttributes at;
@@ -1143,11 +1154,20 @@ int32_t BHR_MARCH_RESOURCES(int32_t *vgprs, int32_t *lds, int32_t diff) {
 int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     const bhr_config &c = ctx->cfg;
 #if !BHR_MARCH_STRICT
-    {
-        bool strict = c.math_mode == BHR_MATH_STRICT;
-        if (flags & BHR_FORCE_FAST) strict = false;
-        if (flags & BHR_FORCE_STRICT) strict = true;
-        if (strict) return bhr_launch_march_strict(ctx, cam, flags);
+    if (!(ctx->part.active && ctx->part.math_resolved)) {
+        int mode = c.math_mode;
+        if (flags & BHR_FORCE_FAST) mode = BHR_MATH_FAST;
+        if (flags & BHR_FORCE_STRICT) mode = BHR_MATH_STRICT;
+        if (flags & BHR_FORCE_HYBRID) mode = BHR_MATH_HYBRID;
+        // hybrid = two launches over complementary tile lists (hybrid.hip); schedules and disk sources that have no
+        // list form run strict
+        // ... and so do views with the LOD anti-aliasing: the mip level is a TRUNCATED function of the ray differentials
+        // (render.py:2987-2988, 2613), so rounding noise in the fast differentials flips the level of the pixels that sit on
+        // a level boundary -- ~300 pixels of a 4k frame by up to 0.8, which alone is 5e-4 RMSE (tools/hybrid_sweep.py)
+        const bool aa = c.anti_alias != 0 && !(flags & BHR_SKIP_DIFFERENTIALS);
+        if (mode == BHR_MATH_HYBRID && (aa || ctx->disk_source != BHR_DISK_TEXTURE || (flags & (BHR_PERSISTENT | BHR_ROW_COSTS)))) mode = BHR_MATH_STRICT;
+        if (mode == BHR_MATH_HYBRID) return bhr_launch_march_hybrid(ctx, cam, flags);
+        if (mode == BHR_MATH_STRICT) return bhr_launch_march_strict(ctx, cam, flags);
     }
 #endif
 #if BHR_MARCH_STRICT && !BHR_MARCH_ILP
@@ -1218,6 +1238,11 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     a.dv2_t_peak = ctx->dv2_norm[2];
     a.tiles_x = (c.width + 7) / 8;
     a.n_tiles = a.tiles_x * ((ctx->rows + 7) / 8);
+    a.n_list = a.n_tiles;
+    // a partial launch (ctx->part: hybrid arithmetic, pipelined row bands) marches the tiles of a caller-made list; the
+    // first part records the start event and clears an untimed counter, the last part records the end event
+    const bhr_march_part part = ctx->part;
+    const bool first_part = !part.active || part.first, last_part = !part.active || part.last;
     a.row_steps = nullptr;
     if (flags & BHR_ROW_COSTS) {
         const size_t n = (size_t)((ctx->rows + 7) / 8);
@@ -1236,7 +1261,10 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         a.wave_stamps = d_stamps;
     }
     a.tile_order = nullptr;
-    {
+    if (part.active) {
+        a.tile_order = part.d_list;
+        a.n_list = part.n;
+    } else {
         const char *e = getenv("BHR_TILE_ORDER");          // "centre" (default) | "row": row-major, for A/B runs
         if (!(e && e[0] == 'r')) {
             BHR_TRY(ensure_tile_order(ctx, a.tiles_x, a.n_tiles));
@@ -1249,18 +1277,20 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     const bool want_diff = c.anti_alias != 0 && !(flags & BHR_SKIP_DIFFERENTIALS);
 
     // ring cells are cleared ahead of time (at reset, then by the previous frame's last kernel)
-    if (slot < 0) BHR_HIP(hipMemsetAsync(a.ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream));
+    if (slot < 0 && first_part) BHR_HIP(hipMemsetAsync(a.ray_steps, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->stream));
     if (flags & BHR_PERSISTENT) BHR_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned int), ctx->stream));
     // timed launches (bhr_render) use their ring slot's events, the others the context's scalar ones
-    BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 0] : ctx->ev[0], ctx->stream));
-    if (!(flags & BHR_PERSISTENT) || a.dv2 || a.row_steps) {   // the persistent schedule has no Disk V2 / row-cost variant
+    if (first_part) BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 0] : ctx->ev[0], ctx->stream));
+    if (part.active && part.n <= 0) {
+        // empty list: nothing to launch
+    } else if (!(flags & BHR_PERSISTENT) || a.dv2 || a.row_steps || part.active) {   // the persistent schedule has no Disk V2 / row-cost variant
         // waves per block: a block keeps its CU slot until its slowest wave has finished, so small
         // blocks shorten the tail; BHR_TILE_BLOCK overrides for experiments
         int bt = 256;
         if (const char *e = getenv("BHR_TILE_BLOCK")) bt = atoi(e);
         if (bt != 64 && bt != 128 && bt != 256) bt = 256;
         const int wpb = bt / 64;
-        dim3 grid((a.n_tiles + wpb - 1) / wpb), block(bt);
+        dim3 grid((a.n_list + wpb - 1) / wpb), block(bt);
         if (ctx->disk_source == BHR_DISK_V2_VOLUME) {   // finite-thickness Disk V2: no texture footprint to track
             hipLaunchKernelGGL((march_tile_kernel<false, 2>), grid, block, 0, ctx->stream, a);
         } else if (a.dv2) {   // analytic Disk V2 source: its own instantiations
@@ -1270,7 +1300,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
                 hipLaunchKernelGGL((march_tile_kernel<false, 1>), grid, block, 0, ctx->stream, a);
 #if BHR_MARCH_STRICT && BHR_MARCH_ILP
         } else {
-            const int waves = (a.n_tiles + BHR_TPW - 1) / BHR_TPW;          // BHR_TPW tiles per wave
+            const int waves = (a.n_list + BHR_TPW - 1) / BHR_TPW;          // BHR_TPW tiles per wave
             const dim3 g((waves + wpb - 1) / wpb);
             if (want_diff)
                 hipLaunchKernelGGL(march_tile_aa_ilp, g, block, 0, ctx->stream, a);
@@ -1298,7 +1328,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
             hipLaunchKernelGGL(march_persistent_kernel<false>, grid, block, 0, ctx->stream, a, refill_below);
     }
     BHR_HIP(hipGetLastError());
-    BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 1] : ctx->ev[1], ctx->stream));
+    if (last_part) BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 1] : ctx->ev[1], ctx->stream));
     if (d_stamps) {
         std::vector<unsigned long long> h((size_t)a.n_tiles * 4);
         BHR_HIP(hipMemcpyAsync(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));

@@ -177,6 +177,31 @@ def assemble_video(temp_dir: str, n_frames: int, fps: int, output_path: str) -> 
     return True
 
 
+def _drop_stream(stream, encoder, err) -> None:
+    """The yuv420p stream is an extra: when its consumer dies (an ffmpeg without libx264 exits at once and every later
+    write fails with EPIPE) the stream is closed, the encoder reaped, and the render goes on with the PNG frames, from
+    which assemble_video builds the MP4 at the end as the reference does (render.py:4497-4503).  Returns None."""
+    print(f"Warning: video stream failed ({err}); continuing with the PNG frames")
+    try:
+        stream.close()
+    except Exception:
+        pass
+    if encoder is not None:
+        try:
+            encoder.stdin.close()
+        except Exception:
+            pass
+        try:
+            encoder.kill()
+        except Exception:
+            pass
+        try:
+            encoder.wait(timeout=10)
+        except Exception:
+            pass
+    return None
+
+
 def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, fps: int, output_path: str,
                  fov: float, static_cam_pos: List[float], orbit: bool = False, resume: bool = False,
                  disk_rotation_speed: float = 0.1, orbit_degrees: float = 360.0, rank: int = 0, world: int = 1,
@@ -222,10 +247,18 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
                     os.remove(os.path.join(temp_dir, f"frame_{fr:04d}.png"))
                 except OSError:
                     pass
-            try:
-                os.remove(progress_file)
-            except OSError:
-                pass
+            # every stale record goes -- also the ones a run with another world size left under the other naming
+            # (progress.json <-> progress.rank<r>.json), or every later --resume would see the mismatch again and start
+            # over for ever.  Rank 0 removes the files no rank of THIS run owns; each rank removes its own.
+            mine = os.path.basename(progress_file)
+            current = {"progress.json"} if world == 1 else {f"progress.rank{r}.json" for r in range(world)}
+            for name in sorted(os.listdir(temp_dir)):
+                is_record = name == "progress.json" or (name.startswith("progress.rank") and name.endswith(".json"))
+                if is_record and (name == mine or (rank == 0 and name not in current)):
+                    try:
+                        os.remove(os.path.join(temp_dir, name))
+                    except OSError:
+                        pass
         elif records:
             done = set()
             for r in records:                                        # a different world size last time: still counted
@@ -273,7 +306,10 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
         renderer.render_async(cam_pos, fov, frame=0)   # lens flare, when enabled, is applied on the device
         sink.submit(os.path.join(temp_dir, f"frame_{frame:04d}.png"))
         if stream is not None:
-            stream.submit()
+            try:
+                stream.submit()
+            except Exception as e:                      # the encoder went away (EPIPE): the PNG frames carry on
+                stream, encoder = _drop_stream(stream, encoder, e), None
         elapsed = time.time() - t0
         rendered += 1
         submitted.append(frame)
@@ -290,7 +326,11 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
     sink.close()
     streamed = False
     if stream is not None:
-        n_streamed, _ = stream.drain()
+        try:
+            n_streamed, _ = stream.drain()
+        except Exception as e:
+            stream, encoder = _drop_stream(stream, encoder, e), None
+    if stream is not None:
         stream.close()
         if encoder is not None:
             encoder.stdin.close()

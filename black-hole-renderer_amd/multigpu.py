@@ -80,13 +80,19 @@ def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
 
 
 def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_differentials=False,
-                 skip_bloom=False, lens_flare=False, gather: str = "host"):
+                 skip_bloom=False, lens_flare=False, gather: str = "host", schedule: str = "pipelined", live=None):
     """Render one frame with the row-block renderers ``tiles`` (HipRenderer objects whose rows tile
     the image in order).  gather="host": returns the (H, W, 3) float32 frame, assembled from per-device pinned
     buffers.  gather="peer": the tiles are gathered on tiles[0]'s device with hipMemcpyPeerAsync (xGMI) and stay
-    there -- returns None, read_gathered(tiles) fetches the frame (bench.py's strong-scaling leg times this one)."""
-    if gather not in ("host", "peer"):
-        raise ValueError(f"gather must be 'host' or 'peer', got {gather!r}")
+    there -- returns None, read_gathered(tiles) fetches the frame.  gather="peer_u8": the same with the quantised
+    rows (a quarter of the bytes; read_gathered_u8).  gather="none": the rows stay in their tiles.
+    schedule: "pipelined" (default; halo bands first, halo pulls and row-chunk pushes under the march / the V pass,
+    csrc/group.hip) or "serial" (step after step; same bytes).  live: per-tile 0/1 -- only those tiles render, the
+    others keep the buffers of the last call in which they did (bench.py times one tile of eight that way)."""
+    if gather not in ("host", "peer", "peer_u8", "none"):
+        raise ValueError(f"gather must be 'host', 'peer', 'peer_u8' or 'none', got {gather!r}")
+    if schedule not in ("pipelined", "serial"):
+        raise ValueError(f"schedule must be 'pipelined' or 'serial', got {schedule!r}")
     first = tiles[0]
     lib = _lib.load()
     arr = (C.c_void_p * len(tiles))(*[t._ctx for t in tiles])
@@ -94,11 +100,19 @@ def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_diff
     flags = first._flags(skip_differentials, skip_bloom)
     if lens_flare:
         flags |= _lib.LENS_FLARE
-    if gather == "peer":
-        _lib.check(lib.bhr_group_render(arr, len(tiles), C.byref(cam), flags | _lib.GATHER_PEER, None))
+    if schedule == "serial":
+        flags |= _lib.GROUP_SERIAL
+    flags |= {"host": 0, "none": 0, "peer": _lib.GATHER_PEER, "peer_u8": _lib.GATHER_U8}[gather]
+    live_arr = None
+    if live is not None:
+        if len(live) != len(tiles):
+            raise ValueError(f"live must have one entry per tile ({len(tiles)}), got {len(live)}")
+        live_arr = (C.c_int32 * len(tiles))(*[1 if v else 0 for v in live])
+    if gather != "host":
+        _lib.check(lib.bhr_group_render_subset(arr, len(tiles), C.byref(cam), flags, None, live_arr))
         return None
     out = np.empty((first.height, first.width, 3), dtype=np.float32)
-    _lib.check(lib.bhr_group_render(arr, len(tiles), C.byref(cam), flags, _lib.fptr(out)))
+    _lib.check(lib.bhr_group_render_subset(arr, len(tiles), C.byref(cam), flags, _lib.fptr(out), live_arr))
     return out
 
 
@@ -107,6 +121,14 @@ def read_gathered(tiles: Sequence) -> np.ndarray:
     first = tiles[0]
     out = np.empty((first.height, first.width, 3), dtype=np.float32)
     _lib.check(_lib.load().bhr_read_gathered(first._ctx, _lib.fptr(out)))
+    return out
+
+
+def read_gathered_u8(tiles: Sequence) -> np.ndarray:
+    """The quantised (H, W, 3) uint8 frame the last group_render(..., gather="peer_u8") left on tiles[0]'s device."""
+    first = tiles[0]
+    out = np.empty((first.height, first.width, 3), dtype=np.uint8)
+    _lib.check(_lib.load().bhr_read_gathered_u8(first._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8))))
     return out
 
 

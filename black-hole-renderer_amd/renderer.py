@@ -55,8 +55,10 @@ class HipRenderer:
         # divide -- ray paths bit-identical to a strict f32 evaluation of render.py:2854-3006.
         # math="fast": 2-D orbital-plane state, v_rsq/v_rcp, fast-math (Taichi's fast_math=True
         # analogue); ~3x faster, deviates from strict by f32 rounding noise only.
-        if math not in ("fast", "strict"):
-            raise ValueError(f"math must be 'fast' or 'strict', got {math!r}")
+        # math="hybrid": the strict kernel on the 8x8 tiles whose rays pass near the photon sphere (impact parameter
+        # within a band around 3 sqrt(3)/2 r_s -- the only rays that amplify rounding), the fast kernel on all others.
+        if math not in ("fast", "strict", "hybrid"):
+            raise ValueError(f"math must be 'fast', 'strict' or 'hybrid', got {math!r}")
         self.math = math
         if anti_alias not in ("disabled", "lod_radius"):
             raise ValueError(f"anti_alias must be 'disabled' or 'lod_radius', got {anti_alias!r}")
@@ -74,7 +76,7 @@ class HipRenderer:
         cfg = _lib.Config(self.width, self.height, self.row0, self.row1, float(step_size), float(r_max),
                           float(r_disk_inner), float(r_disk_outer), float(disk_tilt),
                           0 if anti_alias == "disabled" else 1, float(aa_strength), float(disk_rotation_speed),
-                          self.device_index, _lib.MATH_STRICT if math == "strict" else _lib.MATH_FAST)
+                          self.device_index, {"strict": _lib.MATH_STRICT, "fast": _lib.MATH_FAST, "hybrid": _lib.MATH_HYBRID}[math])
         handle = C.c_void_p()
         # frame_slots: 2 (library default) = successive render_async calls alternate between two frame slots /
         # streams and overlap; 1 = one frame at a time on the context's stream (isolated kernel timing).  The
@@ -366,7 +368,7 @@ class HipRenderer:
     def _flags(skip_differentials: bool, skip_bloom: bool, compaction: bool = False, math=None) -> int:
         return ((_lib.SKIP_DIFFERENTIALS if skip_differentials else 0) | (_lib.SKIP_BLOOM if skip_bloom else 0)
                 | (_lib.PERSISTENT if compaction else 0)
-                | {None: 0, "fast": _lib.FORCE_FAST, "strict": _lib.FORCE_STRICT}[math])
+                | {None: 0, "fast": _lib.FORCE_FAST, "strict": _lib.FORCE_STRICT, "hybrid": _lib.FORCE_HYBRID}[math])
 
     def render_async(self, cam_pos, fov: float, frame: int = 0, skip_differentials: bool = False,
                      skip_bloom: bool = False, compaction: bool = False, math=None, lens_flare=None) -> None:
@@ -436,8 +438,20 @@ class HipRenderer:
         _lib.check(self._lib.bhr_selftest(self._ctx, out))
         return {"bad_sqrt": out[0], "bad_div": out[1], "bad_div6": out[2], "checked": out[3]}
 
+    def hybrid_info(self) -> dict:
+        """Tile split and band of the last math="hybrid" march (bhr_hybrid_info)."""
+        t, b = (C.c_int32 * 2)(), (C.c_double * 2)()
+        _lib.check(self._lib.bhr_hybrid_info(self._ctx, t, b))
+        return {"strict_tiles": int(t[0]), "tiles": int(t[1]), "band_below": float(b[0]), "band_above": float(b[1])}
+
     def timing_reset(self) -> None:
         _lib.check(self._lib.bhr_timing_reset(self._ctx))
+
+    def frame_times(self, n: int) -> np.ndarray:
+        """(n, 3) march start / march end / frame end of the last n timed frames, ms after the oldest one's start."""
+        out = np.empty((n, 3), dtype=np.float32)
+        _lib.check(self._lib.bhr_timing_dump(self._ctx, _lib.fptr(out), n))
+        return out
 
     def counters(self) -> dict:
         c = _lib.Counters()

@@ -65,7 +65,7 @@ typedef struct {
     float aa_strength;          /* default 1.0  */
     float disk_rotation_speed;  /* t_offset = frame * this (render.py:3897) */
     int32_t device;             /* HIP device ordinal */
-    int32_t math_mode;          /* BHR_MATH_FAST (0) or BHR_MATH_STRICT (1) */
+    int32_t math_mode;          /* BHR_MATH_FAST (0), BHR_MATH_STRICT (1) or BHR_MATH_HYBRID (2) */
 } bhr_config;
 
 /* math_mode: FAST uses v_rsq/v_rcp/v_sqrt and FMA contraction inside the RK4 loop (the analogue
@@ -74,6 +74,15 @@ typedef struct {
  * evaluation of the reference, at roughly twice the march time. */
 #define BHR_MATH_FAST 0
 #define BHR_MATH_STRICT 1
+/* HYBRID: the strict arithmetic where the geodesic is unstable, the fast arithmetic elsewhere.  The only rays that
+ * amplify rounding are those whose impact parameter b = |pos x dir| lies near the critical b_c = (3 sqrt 3 / 2) r_s of
+ * the photon sphere (they wind around it; the deflection grows like -ln|b / b_c - 1|).  8x8-pixel tiles whose rays
+ * have b within a band around b_c are marched by the STRICT kernel -- bit-identical paths, as math_mode 1 -- and all
+ * other tiles by the FAST kernel, as two launches over complementary tile lists.  Pixels stay within the 1e-4 bar of
+ * the reference's statements on every fixture; ray-step totals within 2e-4.  Schedules / disk sources
+ * without a tile-list form (BHR_PERSISTENT, BHR_ROW_COSTS, Disk V2) run STRICT, and so do views with anti_alias = 1:
+ * the mip level is a truncated function of the ray differentials, which rounding noise flips on level boundaries. */
+#define BHR_MATH_HYBRID 2
 
 /* Camera uniforms exactly as TaichiRenderer.render() uploads them
  * (render.py:3880-3892): build_camera() in f64 on the host, cast to f32. */
@@ -92,6 +101,12 @@ typedef struct {
 #define BHR_FORCE_STRICT      16u  /* this call only: strict arithmetic regardless of bhr_config.math_mode */
 #define BHR_ROW_COSTS         64u  /* also accumulate ray-steps per 8-row band (bhr_get_row_costs): the cost profile row blocks are balanced with */
 #define BHR_LENS_FLARE        32u  /* add the lens flare to the final layer on the device (render.py:3920-4028) */
+#define BHR_FORCE_HYBRID     256u  /* this call only: hybrid arithmetic regardless of bhr_config.math_mode */
+#define BHR_GATHER_U8        512u  /* bhr_group_render: gather the QUANTISED rows ((H, W, 3) u8, save_image's truncation, render.py:423)
+                                      on ctxs[0]'s device -- a quarter of the f32 bytes over xGMI; the pipelined schedule
+                                      ships every row chunk as soon as its V pass has written it */
+#define BHR_GROUP_SERIAL    1024u  /* bhr_group_render: the serial schedule (march -> H -> halo -> V -> gather per tile) instead
+                                      of the pipelined one; same bytes */
 #define BHR_GATHER_PEER      128u  /* bhr_group_render: gather the tiles into one (H, W, 3) buffer on ctxs[0]'s device with
                                       hipMemcpyPeerAsync (xGMI), one copy per tile on the tile's own stream */
 
@@ -225,12 +240,18 @@ BHR_API int32_t bhr_lens_flare_sums(bhr_ctx *ctx, double *out3);
  * on the device: (row1-row0, width, 3) u8.  Synchronises. */
 BHR_API int32_t bhr_read_final_u8(bhr_ctx *ctx, uint8_t *out);
 BHR_API int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out);
+/* Last BHR_MATH_HYBRID march of this context: out_tiles = {tiles marched strict, tiles of the row block},
+ * out_band = {lo, hi}: the strict band [b_c - lo, b_c + hi] of impact parameters, in r_s. */
+BHR_API int32_t bhr_hybrid_info(bhr_ctx *ctx, int32_t out_tiles[2], double out_band[2]);
 /* Device self-test of the strict march's hand-written exact sqrt / divide / divide-by-6 against the
  * compiler's IEEE sequences: out[0..2] = mismatches (sqrt over every f32 in [2^-80, 2^80); 1/x over
  * the same range plus a/b over 2^30 random pairs; x/6 over the same range), out[3] = comparisons made. */
 BHR_API int32_t bhr_selftest(bhr_ctx *ctx, uint64_t out[4]);
 /* forget the per-frame timing ring (call before a timed region) */
 BHR_API int32_t bhr_timing_reset(bhr_ctx *ctx);
+/* The last n timed bhr_render calls, oldest first: out[3 k .. 3 k + 2] = march start, march end, frame end of frame k in
+ * milliseconds after the oldest frame's march start (HIP events on the frame slots' streams).  Synchronises. */
+BHR_API int32_t bhr_timing_dump(bhr_ctx *ctx, float *out, int32_t n);
 /* Cost of each band of 8 rows in the last bhr_render(..., BHR_ROW_COSTS), in ray-step units: the ray-steps marched
  * plus 320 per wave-wide shading pass.  n = ceil(rows / 8) values.
  * The step count of a ray depends on the camera, the step size and the escape radius only -- not on the
@@ -242,9 +263,19 @@ BHR_API int32_t bhr_get_row_costs(bhr_ctx *ctx, uint64_t *out, int32_t n);
  * contiguous, ordered and cover [0,height).  Marches all tiles concurrently,
  * exchanges the R = int(0.02*W) H-blurred halo rows between neighbours with
  * hipMemcpyPeerAsync, runs the V pass per tile and gathers the final tiles:
- * with BHR_GATHER_PEER into a full-frame buffer on ctxs[0]'s device (peer copies over xGMI, no collective),
- * and, if out_host != NULL, into out_host (H, W, 3) through per-device pinned buffers.  Synchronises. */
+ * with BHR_GATHER_PEER into a full-frame f32 buffer on ctxs[0]'s device, with BHR_GATHER_U8 into a quantised u8 one
+ * (peer copies over xGMI, no collective), and, if out_host != NULL, into out_host (H, W, 3) through per-device pinned
+ * buffers.  Pipelined by default (csrc/group.hip): every tile marches its halo bands first, pulls its neighbours'
+ * halo rows under the march of the remaining rows, and pushes finished row chunks while the next chunk's V pass
+ * runs; BHR_GROUP_SERIAL selects the step-after-step schedule.  Same bytes either way.  Synchronises. */
 BHR_API int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host);
+/* The same with only the tiles k with live[k] != 0 rendering; the others keep the buffers (halo rows, gathered rows,
+ * glow rows) of the last call in which they were live.  live == NULL: all.  Times one tile of N end to end on one
+ * device (bench.py tile_scaling): its counters' frame_ms then spans first march launch .. its rows landed on tile 0. */
+BHR_API int32_t bhr_group_render_subset(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host,
+                                        const int32_t *live);
+/* The quantised frame the last bhr_group_render(..., BHR_GATHER_U8) gathered on this context's device: (H, W, 3) u8. */
+BHR_API int32_t bhr_read_gathered_u8(bhr_ctx *ctx, uint8_t *out);
 /* The frame the last bhr_group_render(..., BHR_GATHER_PEER) gathered on this context's device: (H, W, 3) f32. */
 BHR_API int32_t bhr_read_gathered(bhr_ctx *ctx, float *out);
 

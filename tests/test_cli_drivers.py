@@ -150,6 +150,15 @@ def test_video_frames_resume_and_sharding(tmp_path):
     for k in range(6):
         np.testing.assert_array_equal(np.array(Image.open(os.path.join(d2, f"frame_{k:04d}.png"))), frames1[k])
 
+    # a changed parameter after a run with ANOTHER world size: the stale records of both namings go, so that the next
+    # --resume really resumes instead of starting over for ever (advisor finding, round 2)
+    assert sorted(f for f in os.listdir(d2) if f.startswith("progress")) == ["progress.rank0.json", "progress.rank1.json"]
+    run(out2, n_frames=5, resume=True)                        # world 1, n_frames changed -> start over, once
+    assert sorted(f for f in os.listdir(d2) if f.startswith("progress")) == ["progress.json"]
+    mtime = os.path.getmtime(os.path.join(d2, "frame_0002.png"))
+    run(out2, n_frames=5, resume=True)                        # nothing left to do: no frame is rendered again
+    assert os.path.getmtime(os.path.join(d2, "frame_0002.png")) == mtime
+
 
 def test_disk_model_flag():
     from bhr_amd import cli

@@ -92,3 +92,76 @@ def test_threaded_submission_gives_the_same_frame(hip_lib, monkeypatch):
         np.testing.assert_array_equal(multigpu.read_gathered(tiles), want)
     for t in tiles + [full]:
         t.close()
+
+
+@pytest.mark.parametrize("flare", [False, True])
+def test_pipelined_schedule_equals_serial_bit_for_bit(flare, hip_lib):
+    """The pipelined row-block schedule (halo bands marched first, halo pulls under the march of the middle rows, V pass
+    and pushes in row chunks, csrc/group.hip) against the step-after-step one: same bytes, in every gather mode, with a
+    tile thinner than the bloom radius (two-hop halo) and with the lens flare."""
+    from bhr_amd import multigpu
+    s, tiles, full = _tiles([0, 50, 54, 120, 180], [0, 0, 0, 0], lens_flare=flare)
+    kw = dict(lens_flare=flare)
+    want = multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="host", schedule="serial", **kw)
+    for _ in range(3):
+        got = multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="host", schedule="pipelined", **kw)
+        np.testing.assert_array_equal(got, want)
+    multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="peer", schedule="pipelined", **kw)
+    np.testing.assert_array_equal(multigpu.read_gathered(tiles), want)
+    want_u8 = (np.clip(want, 0, 1) * np.float32(255)).astype(np.uint8)      # save_image's truncation (render.py:423)
+    for sched in ("pipelined", "serial"):
+        multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="peer_u8", schedule=sched, **kw)
+        np.testing.assert_array_equal(multigpu.read_gathered_u8(tiles), want_u8)
+    np.testing.assert_allclose(want, full.render(s["cam_pos"], s["fov"]), atol=1e-6, rtol=0)
+    for t in tiles + [full]:
+        t.close()
+
+
+def test_subset_render_leaves_the_frame_unchanged(hip_lib):
+    """bhr_group_render_subset: one tile re-rendered alone (its neighbours resting) reproduces its rows of the frame."""
+    from bhr_amd import multigpu
+    s, tiles, full = _tiles([0, 48, 96, 136, 180], [0, 0, 0, 0])
+    multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="peer")
+    want = multigpu.read_gathered(tiles)
+    multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="peer_u8")
+    want_u8 = multigpu.read_gathered_u8(tiles)
+    for k in range(4):
+        live = [int(q == k) for q in range(4)]
+        for sched in ("pipelined", "serial"):
+            multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="peer", schedule=sched, live=live)
+            np.testing.assert_array_equal(multigpu.read_gathered(tiles), want)
+            multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="peer_u8", schedule=sched, live=live)
+            np.testing.assert_array_equal(multigpu.read_gathered_u8(tiles), want_u8)
+        assert tiles[k].counters()["frame_ms"] > 0
+    with pytest.raises(ValueError, match="every tile live"):
+        multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="host", live=[1, 0, 0, 0])
+    for t in tiles + [full]:
+        t.close()
+
+
+def test_8k_frame_in_eight_blocks_equals_one_context(hip_lib):
+    """BASELINE.json configs[3] at full size: the 7680x4320 step-0.05 frame cut into 8 cost-balanced row blocks (all on
+    device 0 here), pipelined schedule, against the same frame from one context: every pixel of the gathered f32 frame to
+    1e-6 (the bloom sums its taps tile by tile), the quantised gather equal to the truncation of the f32 gather, ray-step
+    totals equal."""
+    from bhr_amd import HipRenderer, multigpu
+    W, H = 7680, 4320
+    sky, tex = scenes.analytic_skybox(256, 512), scenes.noisy_disk(256, 1024)
+    kw = dict(step_size=0.05, r_max=10.0, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=0.0)
+    cam, fov = [6.0, 0.0, 0.5], 90.0
+    per_row, band_rows = multigpu.probe_row_costs(W, H, cam, fov, **kw)
+    blocks = multigpu.balanced_row_blocks(H, 8, per_row, band_rows, fixed_cost_per_row=0.1 * float(per_row.mean()))
+    full = HipRenderer(W, H, sky, tex, frame_slots=1, **kw)
+    ref = full.render(cam, fov)
+    ref_steps = full.counters()["ray_steps"]
+    full.close()
+    tiles = [HipRenderer(W, H, sky, tex, rows=b, frame_slots=1, **kw) for b in blocks]
+    multigpu.group_render(tiles, cam, fov, gather="peer")
+    got = multigpu.read_gathered(tiles)
+    assert sum(t.counters()["ray_steps"] for t in tiles) == ref_steps
+    d = np.abs(got - ref)
+    assert d.max() <= 1e-6, d.max()
+    multigpu.group_render(tiles, cam, fov, gather="peer_u8")
+    np.testing.assert_array_equal(multigpu.read_gathered_u8(tiles), (np.clip(got, 0, 1) * np.float32(255)).astype(np.uint8))
+    for t in tiles:
+        t.close()

@@ -147,3 +147,25 @@ def test_render_video_pipes_the_stream_into_ffmpeg(tmp_path, monkeypatch):
     assert all(p[0].max() > 40 for p in planes)
     d = drivers._frames_dir(out)
     assert sorted(f for f in os.listdir(d) if f.endswith(".png")) == [f"frame_{k:04d}.png" for k in range(7)]
+
+
+def test_render_video_survives_an_encoder_that_dies(tmp_path, monkeypatch, capsys):
+    """An `ffmpeg` that exits at once (e.g. built without libx264): every later write to the pipe fails with EPIPE.  The
+    stream is dropped, the child reaped, and all PNG frames + progress.json are still written (advisor finding, round 2)."""
+    import json, stat
+    from bhr_amd import drivers
+    fake = tmp_path / "bin" / "ffmpeg"
+    fake.parent.mkdir()
+    fake.write_text('#!/bin/sh\nexit 1\n')
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(fake.parent) + os.pathsep + os.environ["PATH"])
+    out = str(tmp_path / "vid" / "v.mp4")
+    r, _, _, _ = drivers.make_renderer(160, 90, [6, 0, 0.5], 90, n_stars=50, tex_w=256, tex_h=128)
+    drivers.render_video(r, 160, 90, n_frames=40, fps=30, output_path=out, fov=90, static_cam_pos=[6, 0, 0.5], orbit=True,
+                         orbit_degrees=45.0, assemble=True, video_stream="auto")
+    r.close()
+    d = drivers._frames_dir(out)
+    assert sorted(f for f in os.listdir(d) if f.endswith(".png")) == [f"frame_{k:04d}.png" for k in range(40)]
+    assert json.load(open(os.path.join(d, "progress.json")))["completed"] == list(range(40))
+    text = capsys.readouterr().out
+    assert "continuing with the PNG frames" in text or "falling back to the PNG frames" in text
