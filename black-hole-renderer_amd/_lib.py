@@ -24,7 +24,7 @@ SYMBOLS = (
     "bhr_set_skybox", "bhr_skybox_add_glow", "bhr_skybox_build", "bhr_get_skybox", "bhr_set_disk_texture", "bhr_get_disk_texture", "bhr_get_disk_mip", "bhr_num_mip_levels",
     "bhr_bg_init", "bhr_generate_background", "bhr_set_entity_staging", "bhr_set_comp", "bhr_read_comp",
     "bhr_fill_comp_slice", "bhr_set_compose_stats", "bhr_compose_texture", "bhr_eval_noise", "bhr_render",
-    "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_hybrid_info", "bhr_timing_reset", "bhr_timing_dump", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_group_render_subset", "bhr_read_gathered", "bhr_read_gathered_u8", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities", "bhr_accumulate_population",
+    "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_hybrid_info", "bhr_timing_reset", "bhr_timing_dump", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_group_render_subset", "bhr_read_gathered", "bhr_read_gathered_u8", "bhr_tile_export", "bhr_tile_connect", "bhr_tile_render", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities", "bhr_accumulate_population",
     "bhr_stats_prepare", "bhr_stats_select", "bhr_stats_row_statistics",
     "bhr_png_bound", "bhr_png_encode", "bhr_png_write", "bhr_png_device_bound", "bhr_png_device_max_width", "bhr_png_encode_device", "bhr_png_device_menu",
     "bhr_sink_create", "bhr_sink_submit", "bhr_sink_drain",
@@ -52,6 +52,15 @@ class Counters(C.Structure):
                 ("march_vgprs", C.c_int32), ("march_lds_bytes", C.c_int32), ("frames_timed", C.c_int32),
                 ("march_ms_sum", C.c_float), ("bloom_ms_sum", C.c_float), ("ray_steps_sum", C.c_uint64),
                 ("march_busy_ms", C.c_float), ("span_ms", C.c_float)]
+
+
+TILE_SHM_WORDS = 8
+
+
+class TileHandles(C.Structure):
+    _fields_ = [("hblur", C.c_uint8 * 64), ("gather_f32", C.c_uint8 * 64), ("gather_u8", C.c_uint8 * 64),
+                ("row0", C.c_int32), ("rows", C.c_int32), ("device", C.c_int32), ("has_gather_f32", C.c_int32),
+                ("has_gather_u8", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class BhrError(RuntimeError):
@@ -117,6 +126,9 @@ def load() -> C.CDLL:
     lib.bhr_group_render.argtypes = [C.POINTER(P), I32, C.POINTER(Camera), C.c_uint32, F]
     lib.bhr_group_render_subset.argtypes = [C.POINTER(P), I32, C.POINTER(Camera), C.c_uint32, F, C.POINTER(C.c_int32)]
     lib.bhr_read_gathered_u8.argtypes = [P, C.POINTER(C.c_uint8)]
+    lib.bhr_tile_export.argtypes = [P, C.c_uint32, C.POINTER(TileHandles)]
+    lib.bhr_tile_connect.argtypes = [P, I32, I32, C.POINTER(TileHandles), C.POINTER(C.c_uint64)]
+    lib.bhr_tile_render.argtypes = [P, C.POINTER(Camera), C.c_uint32]
     U8, I64 = C.POINTER(C.c_uint8), C.c_int64
     lib.bhr_png_bound.argtypes = [I32, I32]
     lib.bhr_png_encode.argtypes = [U8, I32, I32, I32, I32, U8, I64, C.POINTER(I64)]

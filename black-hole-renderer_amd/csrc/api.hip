@@ -208,6 +208,29 @@ int32_t bhr_fail(int32_t code, const char *fmt, ...) {
     return code;
 }
 
+int32_t bhr_aux_fork(bhr_ctx *ctx) {
+    const int k = ctx->active_slot >= 0 && ctx->active_slot < BHR_MAX_FRAME_SLOTS ? ctx->active_slot : 0;
+    if (!ctx->aux_stream) {
+        int lo = 0, hi = 0;
+        BHR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least priority
+        BHR_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo));
+        for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q) {
+            BHR_HIP(hipEventCreateWithFlags(&ctx->aux_fork[q], hipEventDisableTiming));
+            BHR_HIP(hipEventCreateWithFlags(&ctx->aux_done[q], hipEventDisableTiming));
+        }
+    }
+    BHR_HIP(hipEventRecord(ctx->aux_fork[k], ctx->stream));
+    BHR_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork[k], 0));
+    return BHR_OK;
+}
+
+int32_t bhr_aux_join(bhr_ctx *ctx) {
+    const int k = ctx->active_slot >= 0 && ctx->active_slot < BHR_MAX_FRAME_SLOTS ? ctx->active_slot : 0;
+    BHR_HIP(hipEventRecord(ctx->aux_done[k], ctx->aux_stream));
+    BHR_HIP(hipStreamWaitEvent(ctx->stream, ctx->aux_done[k], 0));
+    return BHR_OK;
+}
+
 int32_t bhr_enter(bhr_ctx *ctx) {
     BHR_HIP(hipSetDevice(ctx->cfg.device));
     for (int k = 0; k < BHR_MAX_FRAME_SLOTS; ++k) {
@@ -343,6 +366,11 @@ void bhr_destroy(bhr_ctx *ctx) {
     bhr_population_free(ctx);
     bhr_hybrid_free(ctx);
     bhr_pipe_free(ctx);
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q) {
+        if (ctx->aux_fork[q]) (void)hipEventDestroy(ctx->aux_fork[q]);
+        if (ctx->aux_done[q]) (void)hipEventDestroy(ctx->aux_done[q]);
+    }
     if (ctx->d_gather_u8) (void)hipFree(ctx->d_gather_u8);
     free(ctx->h_tile_order);
     if (ctx->scene_ev) (void)hipEventDestroy(ctx->scene_ev);

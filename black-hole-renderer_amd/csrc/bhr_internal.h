@@ -177,6 +177,10 @@ struct bhr_ctx {
     int32_t *h_tile_order;     // host copy (malloc)
     int32_t tile_order_n;
     bhr_march_part part;       // partial launch in progress (inactive: whole block)
+    // second march stream (lowest priority): the other half of a split march -- the fast tiles of a hybrid march, the middle
+    // rows of a pipelined row block -- runs beside the first half instead of behind its ragged end (bhr_aux_fork / _join)
+    hipStream_t aux_stream;
+    hipEvent_t aux_fork[BHR_MAX_FRAME_SLOTS], aux_done[BHR_MAX_FRAME_SLOTS];
     void *hybrid;              // hybrid.hip: tile classification cache
     void *pipe;                // group.hip: streams, events and band lists of the pipelined row-block path
     uint8_t *d_gather_u8;      // (H, W, 3) u8: quantised frame gathered from the tiles (BHR_GATHER_U8), on tile 0
@@ -249,6 +253,9 @@ int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, in
 int32_t bhr_bloom_v_tile_rows(bhr_ctx *ctx);                               // output rows per V-pass block
 void bhr_pipe_free(bhr_ctx *ctx);                                          // group.hip
 int32_t bhr_ensure_pinned(bhr_ctx *ctx, size_t bytes);                     // api.hip
+// fork: the aux stream waits for everything ctx->stream has been given so far; join: ctx->stream waits for the aux stream
+int32_t bhr_aux_fork(bhr_ctx *ctx);
+int32_t bhr_aux_join(bhr_ctx *ctx);
 int32_t bhr_launch_flare_glow(bhr_ctx *ctx, bool whole_frame);       // flare.hip
 int32_t bhr_launch_flare_sums(bhr_ctx *ctx);
 int32_t bhr_launch_flare_apply(bhr_ctx *ctx, const double *sums);    // sums == nullptr: device-resident totals

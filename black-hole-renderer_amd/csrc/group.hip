@@ -44,6 +44,16 @@ struct TilePipe {
     int32_t band_top;             // local rows [0, band_top) form the upper halo band (0: none)
     int32_t band_bot;             // local rows [band_bot, rows) the lower one (rows: none)
     int32_t key;                  // 4 | has_up | has_down << 1 once the lists are built
+    // one-process-per-tile variant (bhr_tile_connect): the neighbours' H-blur planes and tile 0's frame buffers, opened
+    // from their IPC handles; counters in host shared memory for the hand-shakes
+    int32_t linked, rank, world;
+    float *nb_hblur[2];           // [0] the tile above, [1] the tile below (nullptr: none)
+    int32_t nb_rows[2];
+    float *gather_f32;            // frame buffers on tile 0's device (its own pointers on rank 0)
+    uint8_t *gather_u8;
+    void *opened[4];              // what hipIpcCloseMemHandle has to release
+    volatile uint64_t *shm;       // BHR_TILE_SHM_WORDS words per rank: [0] frames whose halo bands are H-blurred, [1] frames done
+    uint64_t frame;               // frames rendered through bhr_tile_render
 };
 
 template <typename T>
@@ -327,17 +337,33 @@ int32_t render_pipelined(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t 
                 BHR_HIP(hipEventRecord(p->march_b, c->stream));
                 return BHR_OK;
             }
+            // the halo bands on the tile's stream, the rows between them on its low-priority second stream: they start
+            // together, the bands' workgroups are dispatched first, the rest fills the slots the bands leave -- no drain
+            // between the two launches.  Bracket (start event, counter clear / end event) = empty first / last part.
             bhr_march_part part;
             memset(&part, 0, sizeof(part));
             part.active = 1;
-            part.d_list = p->d_band; part.h_list = p->h_band; part.n = p->n_band; part.id = 1; part.first = 1; part.last = 0;
+            part.id = 1; part.first = 1;
+            c->part = part;
+            BHR_TRY(bhr_launch_march(c, cam, flags));                              // prologue
+            const bool two = !(getenv("BHR_PIPE_MARCH_STREAMS") && atoi(getenv("BHR_PIPE_MARCH_STREAMS")) == 1);
+            if (two) BHR_TRY(bhr_aux_fork(c));
+            part.d_list = p->d_band; part.h_list = p->h_band; part.n = p->n_band; part.first = 0; part.last = 0;
             c->part = part;
             BHR_TRY(bhr_launch_march(c, cam, flags));
             BHR_HIP(hipEventRecord(p->march_a, c->stream));
-            part.d_list = p->d_band + p->n_band; part.h_list = p->h_band + p->n_band; part.n = p->n_rest; part.id = 2; part.first = 0; part.last = 1;
+            hipStream_t main_stream = c->stream;
+            if (two) c->stream = c->aux_stream;
+            part.d_list = p->d_band + p->n_band; part.h_list = p->h_band + p->n_band; part.n = p->n_rest; part.id = 2;
             c->part = part;
-            BHR_TRY(bhr_launch_march(c, cam, flags));
+            const int32_t rc_rest = bhr_launch_march(c, cam, flags);
+            c->stream = main_stream;
+            BHR_TRY(rc_rest);
+            if (two) BHR_TRY(bhr_aux_join(c));
             BHR_HIP(hipEventRecord(p->march_b, c->stream));
+            part.d_list = nullptr; part.h_list = nullptr; part.n = 0; part.last = 1;
+            c->part = part;
+            BHR_TRY(bhr_launch_march(c, cam, flags));                              // epilogue: the end event
             return BHR_OK;
         };
         const int32_t rc_m = march();
@@ -434,6 +460,8 @@ int32_t render_pipelined(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t 
 void bhr_pipe_free(bhr_ctx *ctx) {
     TilePipe *p = (TilePipe *)ctx->pipe;
     if (!p) return;
+    for (void *o : p->opened)
+        if (o) (void)hipIpcCloseMemHandle(o);
     if (p->post) { (void)hipStreamSynchronize(p->post); (void)hipStreamDestroy(p->post); }
     if (p->copy) { (void)hipStreamSynchronize(p->copy); (void)hipStreamDestroy(p->copy); }
     hipEvent_t evs[] = {p->march_a, p->march_b, p->halo_ready, p->h_all, p->halo_in, p->landed, p->post_done, p->glow_ready};
@@ -482,6 +510,227 @@ int32_t bhr_group_render_subset(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam
 
 int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host) {
     return bhr_group_render_subset(ctxs, n, cam, flags, out_host, nullptr);
+}
+
+// ---- one process per tile (bench.py --strong under torchrun when a rank sees only its own GPU) -------------------------
+// Same frame, same kernels, same three streams as the pipelined schedule above; what changes is who talks to whom.  Every
+// rank owns ONE tile.  Device memory crosses the process boundary through hipIpcMemHandle (the neighbours' H-blur planes
+// for the halo pull, tile 0's frame buffers for the push); ordering crosses it through two counters per rank in host
+// shared memory: a rank waits on the HOST for its own halo_ready event, publishes the frame number, and its neighbours
+// queue their halo pulls once they have seen it -- the data is complete by then, no inter-process event is needed.  The
+// frame ends with every rank synchronising its streams and publishing `done`; rank 0 returns when all have.
+int32_t bhr_tile_export(bhr_ctx *ctx, uint32_t gather_flags, bhr_tile_handles *out) {
+    if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_export: bad argument");
+    BHR_TRY(bhr_enter(ctx));
+    memset(out, 0, sizeof(*out));
+    static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(out->hblur), "handle size");
+    hipIpcMemHandle_t h;
+    BHR_HIP(hipIpcGetMemHandle(&h, ctx->d_hblur));
+    memcpy(out->hblur, &h, sizeof(h));
+    out->row0 = ctx->cfg.row0;
+    out->rows = ctx->rows;
+    out->device = ctx->cfg.device;
+    if (ctx->cfg.row0 == 0) {
+        BHR_TRY(ensure_gather(ctx, gather_flags));
+        if (ctx->d_gather) {
+            BHR_HIP(hipIpcGetMemHandle(&h, ctx->d_gather));
+            memcpy(out->gather_f32, &h, sizeof(h));
+            out->has_gather_f32 = 1;
+        }
+        if (ctx->d_gather_u8) {
+            BHR_HIP(hipIpcGetMemHandle(&h, ctx->d_gather_u8));
+            memcpy(out->gather_u8, &h, sizeof(h));
+            out->has_gather_u8 = 1;
+        }
+    }
+    return BHR_OK;
+}
+
+int32_t bhr_tile_connect(bhr_ctx *ctx, int32_t rank, int32_t world, const bhr_tile_handles *all, uint64_t *shm) {
+    if (!ctx || !all || !shm || world < 1 || rank < 0 || rank >= world) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: bad argument");
+    BHR_TRY(bhr_enter(ctx));
+    int expect = 0;
+    for (int k = 0; k < world; ++k) {
+        if (all[k].row0 != expect) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: tile %d starts at row %d, expected %d", k, all[k].row0, expect);
+        expect += all[k].rows;
+        if (world > 1 && all[k].rows < ctx->bloom_R)
+            return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: tile %d has %d rows, fewer than the bloom radius %d (use bhr_group_render)", k, all[k].rows, ctx->bloom_R);
+    }
+    if (expect != ctx->cfg.height || all[rank].row0 != ctx->cfg.row0 || all[rank].rows != ctx->rows)
+        return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: the handles do not describe this frame / this rank's tile");
+    const int with_up = rank > 0, with_down = rank < world - 1;
+    BHR_TRY(ensure_pipe(ctx, with_up, with_down));
+    TilePipe *p = (TilePipe *)ctx->pipe;
+    for (void *&o : p->opened) {
+        if (o) (void)hipIpcCloseMemHandle(o);
+        o = nullptr;
+    }
+    auto open = [&](const uint8_t *raw, void **out, int slot) -> int32_t {
+        hipIpcMemHandle_t h;
+        memcpy(&h, raw, sizeof(h));
+        BHR_HIP(hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess));
+        p->opened[slot] = *out;
+        return BHR_OK;
+    };
+    p->nb_hblur[0] = p->nb_hblur[1] = nullptr;
+    if (with_up) { BHR_TRY(open(all[rank - 1].hblur, (void **)&p->nb_hblur[0], 0)); p->nb_rows[0] = all[rank - 1].rows; }
+    if (with_down) { BHR_TRY(open(all[rank + 1].hblur, (void **)&p->nb_hblur[1], 1)); p->nb_rows[1] = all[rank + 1].rows; }
+    p->gather_f32 = ctx->d_gather;
+    p->gather_u8 = ctx->d_gather_u8;
+    if (rank != 0) {
+        p->gather_f32 = nullptr;
+        p->gather_u8 = nullptr;
+        if (all[0].has_gather_f32) BHR_TRY(open(all[0].gather_f32, (void **)&p->gather_f32, 2));
+        if (all[0].has_gather_u8) BHR_TRY(open(all[0].gather_u8, (void **)&p->gather_u8, 3));
+    }
+    p->rank = rank;
+    p->world = world;
+    p->shm = shm;
+    p->frame = 0;
+    p->linked = 1;
+    return BHR_OK;
+}
+
+namespace {
+// spins until the counter has reached `want`; gives up after ~20 s (a rank that died must not hang the others for ever)
+int32_t wait_counter(volatile uint64_t *c, uint64_t want, const char *what, int peer) {
+    for (uint64_t spins = 0; __atomic_load_n(c, __ATOMIC_ACQUIRE) < want; ++spins) {
+        if ((spins & 0xffff) == 0xffff) {
+            std::this_thread::yield();
+            if (spins > (1ull << 33)) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: timed out waiting for rank %d (%s)", peer, what);
+        }
+    }
+    return BHR_OK;
+}
+}  // namespace
+
+int32_t bhr_tile_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
+    if (!ctx || !cam) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_render: bad argument");
+    TilePipe *p = (TilePipe *)ctx->pipe;
+    if (!p || !p->linked) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: call bhr_tile_connect first");
+    if (flags & BHR_LENS_FLARE) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_render: the lens flare needs the one-process path (bhr_group_render)");
+    if ((flags & BHR_GATHER_PEER) && !p->gather_f32) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: no f32 frame buffer was exported by rank 0");
+    if ((flags & BHR_GATHER_U8) && !p->gather_u8) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: no u8 frame buffer was exported by rank 0");
+    const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
+    const int rank = p->rank, world = p->world;
+    const size_t R = ctx->bloom_R, W = ctx->cfg.width, rows = ctx->rows;
+    const uint64_t frame = ++p->frame;
+    volatile uint64_t *mine = p->shm + (size_t)rank * BHR_TILE_SHM_WORDS;
+    BHR_TRY(bhr_enter(ctx));
+    ctx->cur_slot = -1;
+    ctx->last_slot = -1;
+    const bool split = with_bloom && p->n_band > 0 && p->n_rest > 0 && !(flags & (BHR_PERSISTENT | BHR_ROW_COSTS));
+    // march: halo bands on the tile's stream, the rest on the low-priority second stream (as render_pipelined)
+    auto march = [&]() -> int32_t {
+        if (!split) {
+            BHR_TRY(bhr_launch_march(ctx, cam, flags));
+            BHR_HIP(hipEventRecord(p->march_a, ctx->stream));
+            BHR_HIP(hipEventRecord(p->march_b, ctx->stream));
+            return BHR_OK;
+        }
+        bhr_march_part part;
+        memset(&part, 0, sizeof(part));
+        part.active = 1; part.id = 1; part.first = 1;
+        ctx->part = part;
+        BHR_TRY(bhr_launch_march(ctx, cam, flags));
+        BHR_TRY(bhr_aux_fork(ctx));
+        part.d_list = p->d_band; part.h_list = p->h_band; part.n = p->n_band; part.first = 0;
+        ctx->part = part;
+        BHR_TRY(bhr_launch_march(ctx, cam, flags));
+        BHR_HIP(hipEventRecord(p->march_a, ctx->stream));
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->aux_stream;
+        part.d_list = p->d_band + p->n_band; part.h_list = p->h_band + p->n_band; part.n = p->n_rest; part.id = 2;
+        ctx->part = part;
+        const int32_t rc = bhr_launch_march(ctx, cam, flags);
+        ctx->stream = main_stream;
+        BHR_TRY(rc);
+        BHR_TRY(bhr_aux_join(ctx));
+        BHR_HIP(hipEventRecord(p->march_b, ctx->stream));
+        part.d_list = nullptr; part.h_list = nullptr; part.n = 0; part.last = 1;
+        ctx->part = part;
+        BHR_TRY(bhr_launch_march(ctx, cam, flags));
+        return BHR_OK;
+    };
+    const int32_t rc_m = march();
+    ctx->part.active = 0;
+    BHR_TRY(rc_m);
+    hipStream_t main_stream = ctx->stream;
+    auto on_post = [&](auto f) -> int32_t {
+        ctx->stream = p->post;
+        const int32_t rc = f();
+        ctx->stream = main_stream;
+        return rc;
+    };
+    BHR_TRY(on_post([&]() -> int32_t {
+        BHR_HIP(hipStreamWaitEvent(p->post, p->march_a, 0));
+        if (!split) BHR_HIP(hipStreamWaitEvent(p->post, p->march_b, 0));
+        if (with_bloom && split) {
+            BHR_TRY(bhr_launch_bloom_h_rows(ctx, 0, p->band_top));
+            BHR_TRY(bhr_launch_bloom_h_rows(ctx, p->band_bot, ctx->rows));
+        } else if (with_bloom) {
+            BHR_TRY(bhr_launch_bloom_h(ctx));
+        }
+        BHR_HIP(hipEventRecord(p->halo_ready, p->post));
+        BHR_HIP(hipStreamWaitEvent(p->post, p->march_b, 0));
+        if (with_bloom && split) BHR_TRY(bhr_launch_bloom_h_rows(ctx, p->band_top, p->band_bot));
+        BHR_HIP(hipEventRecord(p->h_all, p->post));
+        return BHR_OK;
+    }));
+    if (with_bloom && world > 1) {
+        // my halo bands are blurred: tell the neighbours; then pull theirs once they have said the same
+        BHR_HIP(hipEventSynchronize(p->halo_ready));
+        __atomic_store_n(mine + 0, frame, __ATOMIC_RELEASE);
+        for (int side = 0; side < 2; ++side) {
+            if (!p->nb_hblur[side]) continue;
+            const int nb = side == 0 ? rank - 1 : rank + 1;
+            BHR_TRY(wait_counter(p->shm + (size_t)nb * BHR_TILE_SHM_WORDS, frame, "halo bands", nb));
+            const size_t nb_rows = p->nb_rows[side], nb_plane = (nb_rows + 2 * R) * W, my_plane = (rows + 2 * R) * W;
+            const size_t src_row = side == 0 ? R + nb_rows - R : R;        // its last / first R rows (own rows live at [R, R + rows))
+            const size_t dst_row = side == 0 ? 0 : R + rows;
+            for (int c = 0; c < 3; ++c)
+                BHR_HIP(hipMemcpyAsync(ctx->d_hblur + c * my_plane + dst_row * W, p->nb_hblur[side] + c * nb_plane + src_row * W,
+                                       R * W * sizeof(float), hipMemcpyDeviceToDevice, p->copy));
+        }
+        BHR_HIP(hipEventRecord(p->halo_in, p->copy));
+        BHR_HIP(hipStreamWaitEvent(p->post, p->halo_in, 0));
+    }
+    // V pass + combine in row chunks, every finished chunk pushed into tile 0's frame buffers by the copy stream
+    int n_chunks_want = 3;
+    if (const char *e = getenv("BHR_TILE_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= PIPE_MAX_CHUNKS) n_chunks_want = v; }
+    const int vb = bhr_bloom_v_tile_rows(ctx);
+    int chunk = (ctx->rows + n_chunks_want - 1) / n_chunks_want;
+    chunk = ((chunk + vb - 1) / vb) * vb;
+    const bool gather = (flags & (BHR_GATHER_PEER | BHR_GATHER_U8)) != 0;
+    BHR_TRY(on_post([&]() -> int32_t {
+        int ci = 0;
+        for (int r0 = 0; r0 < ctx->rows; r0 += chunk, ++ci) {
+            const int r1 = r0 + chunk < ctx->rows ? r0 + chunk : ctx->rows;
+            BHR_TRY(bhr_launch_bloom_v_rows(ctx, with_bloom, r0, r1, (flags & BHR_GATHER_U8) ? ctx->d_final_u8 : nullptr));
+            if (!gather) continue;
+            BHR_HIP(hipEventRecord(p->v_done[ci], p->post));
+            BHR_HIP(hipStreamWaitEvent(p->copy, p->v_done[ci], 0));
+            const size_t W3 = W * 3, off = (size_t)r0 * W3, cnt = (size_t)(r1 - r0) * W3, dst = (size_t)(ctx->cfg.row0 + r0) * W3;
+            if (flags & BHR_GATHER_U8)
+                BHR_HIP(hipMemcpyAsync(p->gather_u8 + dst, ctx->d_final_u8 + off, cnt, hipMemcpyDeviceToDevice, p->copy));
+            if (flags & BHR_GATHER_PEER)
+                BHR_HIP(hipMemcpyAsync(p->gather_f32 + dst, ctx->d_final + off, cnt * sizeof(float), hipMemcpyDeviceToDevice, p->copy));
+        }
+        return BHR_OK;
+    }));
+    BHR_HIP(hipEventRecord(p->post_done, p->post));
+    BHR_HIP(hipEventRecord(p->landed, p->copy));
+    BHR_HIP(hipStreamWaitEvent(ctx->stream, p->post_done, 0));
+    BHR_HIP(hipStreamWaitEvent(ctx->stream, p->landed, 0));
+    BHR_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    ctx->last_flags = (int32_t)flags;
+    ctx->timing_valid = 1;
+    BHR_HIP(hipStreamSynchronize(ctx->stream));
+    // end of frame: my rows have landed and nobody reads my halo rows any more once every rank has said `done`
+    __atomic_store_n(mine + 1, frame, __ATOMIC_RELEASE);
+    for (int k = 0; k < world; ++k)
+        BHR_TRY(wait_counter(p->shm + (size_t)k * BHR_TILE_SHM_WORDS + 1, frame, "end of frame", k));
+    return BHR_OK;
 }
 
 int32_t bhr_read_gathered_u8(bhr_ctx *ctx, uint8_t *out) {

@@ -198,25 +198,39 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
         s.valid = 1;
     }
     const uint32_t f = flags & ~(BHR_FORCE_FAST | BHR_FORCE_STRICT | BHR_FORCE_HYBRID);
-    // longest rays first: the strict tiles are the ones around the photon ring
     bhr_march_part p;
-    p.d_list = s.d_list;
     p.h_list = nullptr;
-    p.n = s.n_strict;
     p.id = id;
     p.active = 1;
     p.math_resolved = 1;
-    p.first = base.active ? base.first : 1;
-    p.last = 0;
-    ctx->part = p;
-    int32_t rc = bhr_launch_march_strict(ctx, cam, f);
-    if (rc == BHR_OK) {
-        p.d_list = s.d_list + s.n_strict;
-        p.n = base_n - s.n_strict;
-        p.first = 0;
-        p.last = base.active ? base.last : 1;
+    // Two launches.  On ONE stream the fast list waits for the last strict wave (the chip drains in between); on TWO the
+    // fast tiles run on the context's low-priority second stream beside the strict ones and fill the slots they leave.
+    // The bracket (start event, counter clear / end event) is an empty first / last part on the frame's own stream.
+    int streams = 2;
+    if (const char *e = getenv("BHR_HYBRID_STREAMS")) streams = atoi(e) == 1 ? 1 : 2;
+    if (base.active) streams = 1;                    // a pipelined row block already runs its two halves on two streams
+    int32_t rc = BHR_OK;
+    auto launch = [&](const int32_t *list, int n, int first, int last, bool strict) -> int32_t {
+        p.d_list = list; p.n = n; p.first = first; p.last = last;
         ctx->part = p;
-        rc = bhr_launch_march(ctx, cam, f);
+        return strict ? bhr_launch_march_strict(ctx, cam, f) : bhr_launch_march(ctx, cam, f);
+    };
+    if (streams == 1) {
+        // longest rays first: the strict tiles are the ones around the photon ring
+        rc = launch(s.d_list, s.n_strict, base.active ? base.first : 1, 0, true);
+        if (rc == BHR_OK) rc = launch(s.d_list + s.n_strict, base_n - s.n_strict, 0, base.active ? base.last : 1, false);
+    } else {
+        hipStream_t main_stream = ctx->stream;
+        rc = launch(nullptr, 0, 1, 0, true);                                       // prologue on the frame's stream
+        if (rc == BHR_OK) rc = bhr_aux_fork(ctx);
+        if (rc == BHR_OK) rc = launch(s.d_list, s.n_strict, 0, 0, true);
+        if (rc == BHR_OK) {
+            ctx->stream = ctx->aux_stream;
+            rc = launch(s.d_list + s.n_strict, base_n - s.n_strict, 0, 0, false);
+            ctx->stream = main_stream;
+        }
+        if (rc == BHR_OK) rc = bhr_aux_join(ctx);
+        if (rc == BHR_OK) rc = launch(nullptr, 0, 0, 1, true);                     // epilogue: the end event
     }
     ctx->part = base;
     return rc;

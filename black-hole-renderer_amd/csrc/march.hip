@@ -228,6 +228,9 @@ __device__ __forceinline__ V3 apply_g_factor(const BhrMarchArgs &a, V3 base_colo
                                              V3 ray_dir_to_cam) {
     const float rs_f = BHR_RS;
     V3 cam_pos = ld3(a.cp);
+    // |cam| is the same for every hit, so the compiler hoists it out of the march loop and keeps it in a VGPR for the
+    // whole march (the strict AA kernel spilled it at 128 VGPRs).  Shading runs a handful of times per ray: recompute.
+    asm volatile("" : "+v"(cam_pos.x));
     float r_obs = sqrtf(dot(cam_pos, cam_pos));
     float r_em = sqrtf(dot(hit_pos, hit_pos));
     float r_safe = fmaxf(r_em, rs_f + 1e-3f);
@@ -663,6 +666,7 @@ struct Ray {
         }
     }
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, d, sh); }
+    __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int at) { write_pixel(a, at, done == 2, d, sh); }
 };
 
 #else
@@ -882,6 +886,7 @@ struct Ray {
         }
     }
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, to3d(du, dw), sh); }
+    __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int at) { write_pixel(a, at, done == 2, to3d(du, dw), sh); }
 };
 #endif  // BHR_MARCH_STRICT
 
@@ -914,6 +919,7 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
     const int i = tx * 8 + (lane & 7);
     const int j = ty * 8 + (lane >> 3);
     const bool valid = tile < a.n_tiles && i < a.width && j < a.rows;
+    // (slot, tile, tx, ty are wave-uniform: march_tile_kernel / march_tiles_of_wave hand over a readfirstlane'd slot)
 
 #if BHR_WAVE_STAMPS_BUILD
     const unsigned long long t_start = a.wave_stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -921,22 +927,28 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
     Ray<DIFF, SRC> ray;
     ray.init(a, valid ? i : 0, valid ? j : 0);
     if (!valid) ray.done = 4;
-    unsigned int executed = 0;
     // Divergent loop: a lane leaves when its ray terminates, the wave leaves when its EXEC mask is
     // empty (the hardware form of "loop while __ballot(alive)").  Written without an inner `if` because
     // hipcc otherwise shuttles the whole ray state through v_mov at every iteration (24 moves/step).
     unsigned int flushes = 0;     // wave-uniform
     while (ray.done == 0) {
-        const bool blocked = !ray.step(a);
-        executed += blocked ? 0u : 1u;
-        // some live lane has filled its parking slots (or, strict AA, found its only slot occupied and will
-        // repeat the step): every live lane shades its older crossing
-        if (__ballot(blocked || ray.n_pend == 2)) { ray.flush_one(a); flushes += 1u; }
+        ray.step(a);
+        // some live lane has filled both its parking slots: every live lane shades its older crossing
+        if (__ballot(ray.n_pend == 2)) { ray.flush_one(a); flushes += 1u; }
     }
     if (__ballot(ray.n_pend > 0)) { ray.flush_one(a); flushes += 1u; }
     if (__ballot(ray.n_pend > 0)) { ray.flush_one(a); flushes += 1u; }
-    if (valid) ray.finish(a);
-    unsigned long long tot = wave_sum_u32(executed);
+    {
+        // The lane's pixel, worked out AGAIN from the thread index behind an optimisation barrier: nothing that is
+        // only needed here (pixel index, validity, store addresses) stays in a register across the march loop -- the
+        // strict AA kernel spilled five such values at 128 VGPRs (round 2: 6 spills, 28 B of scratch).
+        int t2 = threadIdx.x;
+        asm volatile("" : "+v"(t2));
+        const int i2 = tx * 8 + (t2 & 7), j2 = ty * 8 + ((t2 & 63) >> 3);
+        if (tile < a.n_tiles && i2 < a.width && j2 < a.rows) ray.finish_at(a, j2 * a.width + i2);
+    }
+    // a lane executes one step per loop iteration: its step count is the number of steps it executed (0: no ray)
+    unsigned long long tot = wave_sum_u32((unsigned int)ray.step_count);
     if (lane == 0) {
         atomicAdd(a.ray_steps + (size_t)(blockIdx.x & (BHR_STEP_LANES - 1)) * BHR_STEP_STRIDE, tot);
         // BHR_ROW_COSTS: cost profile over tile rows = ray-steps + the wave's shading passes, each priced as
@@ -956,7 +968,7 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
 
 template <bool DIFF, int SRC = 0>
 __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
-    march_tile_body<DIFF, SRC>(a, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    march_tile_body<DIFF, SRC>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
 #if BHR_MARCH_STRICT && BHR_MARCH_ILP
@@ -977,7 +989,7 @@ __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
 #endif
 template <bool DIFF>
 __device__ __forceinline__ void march_tiles_of_wave(const BhrMarchArgs &a) {
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
 #pragma unroll 1
     for (int t = 0; t < BHR_TPW; ++t) {
         const int slot = wave + t * n_waves;
@@ -1154,7 +1166,7 @@ int32_t BHR_MARCH_RESOURCES(int32_t *vgprs, int32_t *lds, int32_t diff) {
 int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     const bhr_config &c = ctx->cfg;
 #if !BHR_MARCH_STRICT
-    if (!(ctx->part.active && ctx->part.math_resolved)) {
+    if (!(ctx->part.active && (ctx->part.math_resolved || ctx->part.n <= 0))) {   // an empty part only records the bracket events
         int mode = c.math_mode;
         if (flags & BHR_FORCE_FAST) mode = BHR_MATH_FAST;
         if (flags & BHR_FORCE_STRICT) mode = BHR_MATH_STRICT;

@@ -47,6 +47,21 @@ def host_barrier(dist=None) -> None:
     dist.barrier(group=_host_group)
 
 
+def host_all_gather_bytes(payload: bytes, dist=None):
+    """All-gather of one bytes object per rank over the host (gloo) group -- the exchange multigpu.TileLink needs."""
+    global _host_group
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [payload]
+    group = None
+    if dist.get_backend() != "gloo":
+        if _host_group is None:
+            _host_group = dist.new_group(backend="gloo")
+        group = _host_group
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, payload, group=group)
+    return out
+
+
 def aggregate_throughput(elapsed_s: float, units: float, dist=None, device="cpu") -> Tuple[float, float]:
     """Whole-job figures for weak scaling: (max over ranks of the elapsed time, sum over ranks of the
     units each rank processed).  Without a process group returns the inputs."""

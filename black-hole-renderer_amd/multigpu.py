@@ -132,6 +132,84 @@ def read_gathered_u8(tiles: Sequence) -> np.ndarray:
     return out
 
 
+class TileLink:
+    """One rank's end of the one-process-per-tile row-block path (include/bhr.h: bhr_tile_export / _connect / _render):
+    every rank owns one HipRenderer whose rows are its block of the frame; the neighbours' halo rows and rank 0's frame
+    buffers are reached through HIP IPC memory handles, the ranks pace each other through counters in host shared memory.
+
+    ``exchange(payload: bytes) -> list[bytes]`` is any all-gather over the ranks (torch.distributed.all_gather_object,
+    files ...); ``shm_name`` names the shared-memory block (rank 0 creates it)."""
+
+    def __init__(self, renderer, rank: int, world: int, exchange, shm_name: str, gather: str = "peer_u8"):
+        from multiprocessing import shared_memory
+        if gather not in ("peer", "peer_u8", "none"):
+            raise ValueError(f"gather must be 'peer', 'peer_u8' or 'none', got {gather!r}")
+        self.renderer, self.rank, self.world, self.gather = renderer, rank, world, gather
+        self._lib = _lib.load()
+        self._gflag = {"peer": _lib.GATHER_PEER, "peer_u8": _lib.GATHER_U8, "none": 0}[gather]
+        nbytes = world * _lib.TILE_SHM_WORDS * 8
+        self._shm = None
+        if rank == 0:
+            try:
+                shared_memory.SharedMemory(name=shm_name).unlink()          # a crashed earlier run
+            except FileNotFoundError:
+                pass
+            self._shm = shared_memory.SharedMemory(name=shm_name, create=True, size=nbytes)
+            self._shm.buf[:nbytes] = bytes(nbytes)
+        mine = _lib.TileHandles()
+        _lib.check(self._lib.bhr_tile_export(renderer._ctx, self._gflag, C.byref(mine)))
+        everyone = exchange(bytes(mine))                                     # also the barrier behind rank 0's create
+        if len(everyone) != world:
+            raise ValueError(f"exchange returned {len(everyone)} records for {world} ranks")
+        if self._shm is None:
+            self._shm = shared_memory.SharedMemory(name=shm_name)
+        arr = (_lib.TileHandles * world)(*[_lib.TileHandles.from_buffer_copy(b) for b in everyone])
+        self._words = (C.c_uint64 * (world * _lib.TILE_SHM_WORDS)).from_buffer(self._shm.buf)
+        _lib.check(self._lib.bhr_tile_connect(renderer._ctx, rank, world, arr, self._words))
+
+    def render(self, cam_pos, fov: float, frame: int = 0, skip_bloom: bool = False) -> None:
+        """One frame: this rank's tile, pipelined; returns when every rank's rows have landed on rank 0's device."""
+        r = self.renderer
+        cam = r.camera_uniforms(cam_pos, fov, frame)
+        _lib.check(self._lib.bhr_tile_render(r._ctx, C.byref(cam), r._flags(False, skip_bloom) | self._gflag))
+
+    def read_gathered(self) -> np.ndarray:
+        return (read_gathered if self.gather == "peer" else read_gathered_u8)([self.renderer])
+
+    def close(self) -> None:
+        if self._shm is not None:
+            del self._words                                                  # releases the exported buffer view
+            self._shm.close()
+            if self.rank == 0:
+                try:
+                    self._shm.unlink()
+                except FileNotFoundError:
+                    pass
+            self._shm = None
+
+
+def file_exchange(directory: str, rank: int, world: int, tag: str = "h", timeout: float = 60.0):
+    """An all-gather through files in ``directory`` (tests, launchers without torch.distributed)."""
+    import time
+
+    def exchange(payload: bytes):
+        tmp = os.path.join(directory, f".{tag}{rank}.tmp")
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, os.path.join(directory, f"{tag}{rank}.bin"))
+        out, t0 = [], time.time()
+        for k in range(world):
+            path = os.path.join(directory, f"{tag}{k}.bin")
+            while not os.path.isfile(path):
+                if time.time() - t0 > timeout:
+                    raise TimeoutError(f"rank {rank}: no record from rank {k} after {timeout:.0f} s")
+                time.sleep(0.005)
+            with open(path, "rb") as f:
+                out.append(f.read())
+        return out
+    return exchange
+
+
 def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devices=None, balance=True, **kw) -> np.ndarray:
     """render_image over ``gpus`` row blocks.  ``devices`` maps block k to a HIP device ordinal
     (default k); every device builds the same deterministic scene.  ``balance``: cut the rows by the cost

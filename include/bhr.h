@@ -276,6 +276,31 @@ BHR_API int32_t bhr_group_render_subset(bhr_ctx **ctxs, int32_t n, const bhr_cam
                                         const int32_t *live);
 /* The quantised frame the last bhr_group_render(..., BHR_GATHER_U8) gathered on this context's device: (H, W, 3) u8. */
 BHR_API int32_t bhr_read_gathered_u8(bhr_ctx *ctx, uint8_t *out);
+
+/* ---- multi-GPU row-block tiling, one PROCESS per tile ------------------------------------------------------------
+ * The same frame and the same pipelined schedule with every tile in its own process (one rank per GPU under
+ * torch.distributed.run, each seeing only its device).  Device buffers cross the process boundary as HIP IPC memory
+ * handles, ordering as two counters per rank in host shared memory; no collective, no inter-process event.
+ *   1. every rank: bhr_tile_export(ctx, BHR_GATHER_U8 and / or BHR_GATHER_PEER, &mine) -- rank 0 (the tile with row0 = 0)
+ *      allocates the frame buffers and exports them with its H-blur planes;
+ *   2. the ranks exchange the bhr_tile_handles records (any host channel: gloo all_gather, a file ...) and agree on a
+ *      zero-initialised shared-memory area of world * BHR_TILE_SHM_WORDS uint64 words;
+ *   3. every rank: bhr_tile_connect(ctx, rank, world, all, shm) -- opens the neighbours' planes and rank 0's buffers;
+ *   4. per frame, every rank: bhr_tile_render(ctx, cam, flags) -- returns when EVERY rank's rows have landed;
+ *      rank 0 then reads the frame with bhr_read_gathered / bhr_read_gathered_u8.
+ * Tiles must be at least R = int(0.02 W) rows high; the lens flare (frame sums) needs bhr_group_render. */
+#define BHR_TILE_SHM_WORDS 8
+typedef struct {
+    uint8_t hblur[64];          /* hipIpcMemHandle_t of the tile's H-blur planes (3, rows + 2R, W) */
+    uint8_t gather_f32[64];     /* rank 0: the (H, W, 3) f32 frame buffer */
+    uint8_t gather_u8[64];      /* rank 0: the (H, W, 3) u8 frame buffer */
+    int32_t row0, rows, device;
+    int32_t has_gather_f32, has_gather_u8;
+    int32_t reserved[3];
+} bhr_tile_handles;
+BHR_API int32_t bhr_tile_export(bhr_ctx *ctx, uint32_t gather_flags, bhr_tile_handles *out);
+BHR_API int32_t bhr_tile_connect(bhr_ctx *ctx, int32_t rank, int32_t world, const bhr_tile_handles *all, uint64_t *shm);
+BHR_API int32_t bhr_tile_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);
 /* The frame the last bhr_group_render(..., BHR_GATHER_PEER) gathered on this context's device: (H, W, 3) f32. */
 BHR_API int32_t bhr_read_gathered(bhr_ctx *ctx, float *out);
 

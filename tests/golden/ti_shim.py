@@ -17,8 +17,9 @@ semantics Taichi documents for them:
   minus, indexing, ``dot``, ``cross``, ``norm`` (= sqrt of the left-to-right sum of squares),
   ``normalized`` (= ``(1 / norm) * v``, taichi's definition with eps = 0).
 * ``ti.cast(x, ti.i32)`` truncates toward zero; integer ``%`` is Python's own (floored), which is
-  what Taichi specifies; ``ti.pow`` with an integer exponent multiplies (Taichi demotes integer
-  powers to multiplications), otherwise it is ``pow``.
+  what Taichi specifies; ``ti.pow`` -- and the ``**`` operator on f32 values, which Taichi maps to it --
+  with an integer exponent multiplies (Taichi demotes integer powers to multiplications), otherwise
+  it is ``pow``.
 * ``ti.sqrt/exp/log/sin/cos/tan/acos/atan2/floor/abs/min/max``, ``ti.math.pi``, ``ti.math.clamp``,
   ``ti.ndrange``, ``ti.init`` (no-op), ``ti.template``, ``ti.f32``, ``ti.i32``, ``ti.cpu``, ``ti.gpu``.
 
@@ -63,7 +64,45 @@ cpu, gpu = "cpu", "gpu"
 _TEMPLATE = object()
 
 _MODE = "f64"
-_F32 = np.float32
+
+
+def _wrap(name):
+    base = getattr(np.float32, name)
+
+    def op(self, other):
+        r = base(self, other)
+        return _F32(r) if type(r) is np.float32 else r      # NotImplemented (Vector operand) passes through
+
+    op.__name__ = name
+    return op
+
+
+class _F32(np.float32):
+    """The f32 scalar of the "f32" mode: numpy.float32 with one difference -- ``x ** n`` with an integer n multiplies
+    (``pow`` below), as Taichi's ``**`` does (it is ``ti.pow``, and integer powers are demoted to multiplications),
+    where numpy.float32.__pow__ would call powf (render.py:2452, 2574, 2606: ``r_safe ** 3``).  Every arithmetic result
+    is again an _F32, so the rule holds wherever a ``**`` is applied."""
+    __slots__ = ()
+
+    def __pow__(self, other, mod=None):
+        return pow(self, other)
+
+    def __rpow__(self, other, mod=None):
+        return pow(other, self)
+
+    def __neg__(self):
+        return _F32(np.float32.__neg__(self))
+
+    def __pos__(self):
+        return self
+
+    def __abs__(self):
+        return _F32(np.float32.__abs__(self))
+
+
+for _name in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__",
+              "__floordiv__", "__rfloordiv__", "__mod__", "__rmod__"):
+    setattr(_F32, _name, _wrap(_name))
 
 
 def set_default_fp(mode):

@@ -1,0 +1,52 @@
+"""Row blocks with one PROCESS per tile (bhr_tile_export / _connect / _render: HIP IPC memory handles + shared-memory
+counters): three processes share the test box's card, each renders its block of the frame, rank 0 ends up with the
+frame -- equal to the frame of one context."""
+import os
+import subprocess
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+from bhr_amd import scenes
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(tmp_path, world, gather, frames=3, math="strict"):
+    shm = "bhr_test_" + uuid.uuid4().hex[:12]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "ipc_tile_worker.py"), str(tmp_path), str(k), str(world), shm,
+                               gather, str(frames), math], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for k in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for k, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {k}:\n{outs[k][-3000:]}"
+    return np.load(os.path.join(tmp_path, "frame.npy")), sum(int(np.load(os.path.join(tmp_path, f"steps{k}.npy"))[0]) for k in range(world))
+
+
+@pytest.mark.parametrize("world,gather", [(3, "peer"), (2, "peer_u8")])
+def test_one_process_per_tile_equals_one_context(tmp_path, world, gather, hip_lib):
+    from bhr_amd import HipRenderer
+    got, steps = _run(tmp_path, world, gather)
+    s = scenes.SCENES["default"]
+    full = HipRenderer(640, 360, scenes.analytic_skybox(), scenes.noisy_disk(), frame_slots=1, **s["kw"])
+    ref = full.render(s["cam_pos"], s["fov"])
+    assert steps == full.counters()["ray_steps"]
+    if gather == "peer":
+        np.testing.assert_allclose(got, ref, atol=1e-6, rtol=0)
+    else:
+        want = full.read_final_u8()
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-4, (d.max(), (d > 0).mean())   # 1e-6 of bloom rounding across a truncation
+    full.close()
