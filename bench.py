@@ -70,7 +70,10 @@ def parse():
     ap.add_argument("--video-frames", type=int, default=300,
                     help="informational leg at N = 1: frames of the video driver's loop (configs[4]: orbit, lifecycle texture "
                          "every frame, PNG files written); 0 skips it")
-    ap.add_argument("--math", default=None, choices=["fast", "strict", "hybrid"], help="march arithmetic (default: the renderer's)")
+    ap.add_argument("--math", default="hybrid", choices=["fast", "strict", "hybrid"],
+                    help="march arithmetic of the headline (default hybrid: strict on the tiles whose rays pass near the photon "
+                         "sphere, fast elsewhere; certified within the north-star tolerance by tests/test_gpu_hybrid.py).  The other "
+                         "two are timed beside it as `other_math`")
     ap.add_argument("--spin-up-ms", type=float, default=60.0,
                     help="un-timed frames rendered for this long BEFORE the --warmup steps: the scene set-up leaves the GPU idle "
                          "and its clocks low, and they take ~20 ms of load to come back (tools/exp_bench_ramp.py)")
@@ -374,20 +377,30 @@ def main():
 
     c = renderer.counters()
     steps_per_frame = c["ray_steps"]
+    hybrid_note = None
+    if renderer.math == "hybrid":
+        try:
+            hi = renderer.hybrid_info()
+            hybrid_note = (f"strict on {hi['strict_tiles']} of {hi['tiles']} 8x8 tiles (impact parameter within "
+                           f"[b_c - {hi['band_below']:g}, b_c + {hi['band_above']:g}] r_s of the photon sphere's 3 sqrt(3)/2), fast on the rest")
+        except Exception:      # a view that ran strict (anti-aliasing on)
+            hybrid_note = "this view runs strict (LOD anti-aliasing on)"
 
-    # same scene, same process, the other arithmetic: reported beside the headline, never as `value`
-    other = "fast" if renderer.math == "strict" else "strict"
+    # same scene, same process, the other arithmetics: reported beside the headline, never as `value`
     n_other = 0 if args.no_other_math else max(args.steps // 4, 10)
-    for _ in range(3 if n_other else 0):
-        renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, math=other)
-    renderer.timing_reset()
-    renderer.sync()
-    t1 = time.perf_counter()
-    for _ in range(n_other):
-        renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, math=other)
-    renderer.sync()
-    el_other = time.perf_counter() - t1
-    co = renderer.counters() if n_other else None
+    others = []
+    for other in [m for m in ("strict", "hybrid", "fast") if m != renderer.math] if n_other else []:
+        for _ in range(3):
+            renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, math=other, lens_flare=flare)
+        renderer.timing_reset()
+        renderer.sync()
+        t1 = time.perf_counter()
+        for _ in range(n_other):
+            renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, math=other, lens_flare=flare)
+        renderer.sync()
+        el_other = time.perf_counter() - t1
+        co = renderer.counters()
+        others.append({"math": other, "value": co["ray_steps"] * n_other / el_other / 1e6, "unit": "Mray-steps/s", "fps": n_other / el_other})
     # Per-kernel durations of ISOLATED launches (one frame slot, one stream): in the timed region above two frames
     # are in flight, their kernels overlap and a launch's own event bracket also covers time it shares with the
     # other frame's kernels.  The roofline below describes the kernel, so it is taken from launches that have the
@@ -469,7 +482,7 @@ def main():
                        "scene": scene_note, "frames_per_rank": args.steps,
                        "sharding": "independent frames per rank, no collective",
                        "march_schedule": "persistent+refill" if args.persistent else "tile",
-                       "march_math": renderer.math, "frame_slots": renderer.frame_slots,
+                       "march_math": renderer.math, "march_math_note": hybrid_note, "frame_slots": renderer.frame_slots,
                        "spin_up": f"{n_spin} un-timed frames ({args.spin_up_ms:g} ms) before the {args.warmup} warm-up steps",
 
                        "ray_steps_per_frame": int(steps_per_frame), "steps_per_ray": steps_per_frame / pixels},
@@ -497,10 +510,9 @@ def main():
                               "unit": "TFLOP/s", "frac": valu_tflops / VALU_FP32_PEAK_TFLOPS,
                               "flop_per_ray_step": MARCH_FLOP_PER_RAY_STEP},
         }
-        if n_other:
-          out["other_math"] = {"math": other, "value": co["ray_steps"] * n_other / el_other / 1e6, "unit": "Mray-steps/s",
-                             "fps": n_other / el_other,
-                             "note": "informational A/B in the same process; `value` above is the default (parity-certified) arithmetic"}
+        if others:
+            out["other_math"] = {"runs": others,
+                                 "note": "informational A/B in the same process and scene; `value` above is --math " + renderer.math}
         if tile is not None:
             out["tile_scaling"] = tile
             # what ONE GPU can show of the 8-GPU leg: one tile of eight, alone on the device, timed end to end

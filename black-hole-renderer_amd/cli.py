@@ -51,6 +51,12 @@ def parse_args(argv=None) -> argparse.Namespace:
                    help="disk source of still images: the lifecycle texture (default), the analytic Disk V2 model at "
                         "each plane crossing, or its finite-thickness emission-absorption integral")
     p.add_argument("--gpus", type=int, default=1, help="row-block tile a still image over N GPUs of this node")
+    p.add_argument("--math", type=str, default="hybrid", choices=["hybrid", "strict", "fast"],
+                   help="march arithmetic.  strict: the reference's operations one by one with exactly rounded sqrt / divide "
+                        "(ray paths bit-identical to an IEEE f32 evaluation of the reference).  hybrid (default): strict on the "
+                        "8x8 tiles whose rays pass near the photon sphere, the fast arithmetic elsewhere -- within 3e-5 RMSE of "
+                        "strict, 1.7x faster; views with --anti_alias lod_radius run strict.  fast: v_rsq / v_rcp + fast-math "
+                        "everywhere (the analogue of Taichi's fast_math=True)")
     p.add_argument("--video_stream", type=str, default="auto", choices=["auto", "y4m", "off"],
                    help="--video: also hand the frames to the encoder as a yuv420p stream converted on the device "
                         "(auto: pipe into ffmpeg when it is on PATH; y4m: write <output stem>.y4m; off: PNG frames only)")
@@ -118,7 +124,7 @@ def main(argv=None) -> int:
         renderer, _, _, _ = drivers.make_renderer(
             width, height, args.pov, fov, args.step_size, args.texture, args.n_stars, 2048, 1024, args.r_max, None,
             args.disk_inner_radius, args.disk_outer_radius, args.disk_tilt, args.lens_flare, args.anti_alias,
-            args.aa_strength, args.disk_rotation_speed, device_index=local_rank)
+            args.aa_strength, args.disk_rotation_speed, device_index=local_rank, math=args.math)
         print(f"Rendering video: {args.n_frames} frames at {width}x{height} (rank {rank}/{world})")
         drivers.render_video(renderer, width, height, n_frames=args.n_frames, fps=args.fps,
                              output_path=args.output, fov=fov, static_cam_pos=args.pov, orbit=args.orbit,
@@ -145,6 +151,6 @@ def main(argv=None) -> int:
         disk_texture_path=args.disk_texture, r_disk_inner=args.disk_inner_radius,
         r_disk_outer=args.disk_outer_radius, disk_tilt=args.disk_tilt, lens_flare=args.lens_flare,
         anti_alias=args.anti_alias, aa_strength=args.aa_strength, disk_rotation_speed=args.disk_rotation_speed,
-        gpus=args.gpus, disk_model=args.disk_model)
+        gpus=args.gpus, disk_model=args.disk_model, math=args.math)
     drivers.save_image(img, args.output)
     return 0

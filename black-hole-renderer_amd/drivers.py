@@ -82,7 +82,7 @@ def use_analytic_disk(renderer: HipRenderer, disk_model: str) -> bool:
 def make_renderer(width, height, cam_pos, fov, step_size=0.1, skybox_path=None, n_stars=6000, tex_w=2048,
                   tex_h=1024, r_max=10.0, disk_texture_path=None, r_disk_inner=R_DISK_INNER_DEFAULT,
                   r_disk_outer=R_DISK_OUTER_DEFAULT, disk_tilt=0.0, lens_flare=False, anti_alias="disabled",
-                  aa_strength=1.0, disk_rotation_speed=0.1, device_index=0, rows=None, frame_slots=None):
+                  aa_strength=1.0, disk_rotation_speed=0.1, device_index=0, rows=None, frame_slots=None, math=None):
     """Renderer with a placeholder (or file) disk texture, as the reference's entry points build it
     (render.py:4044-4064, 4627-4644).  Returns (renderer, use_lifecycle, n_r, n_phi)."""
     # procedural sky: the host draws its random tables, the device rasterises them (nebula resize, star blobs in
@@ -105,7 +105,7 @@ def make_renderer(width, height, cam_pos, fov, step_size=0.1, skybox_path=None, 
                            r_disk_inner=r_disk_inner, r_disk_outer=r_disk_outer, disk_tilt=disk_tilt,
                            lens_flare=lens_flare, anti_alias=anti_alias, aa_strength=aa_strength,
                            disk_rotation_speed=disk_rotation_speed, device_index=device_index, rows=rows,
-                           frame_slots=frame_slots)
+                           frame_slots=frame_slots, **({} if math is None else {"math": math}))
     if procedural_sky:
         renderer.build_procedural_skybox(seed=42, n_stars=n_stars)
     return renderer, use_lifecycle, n_r, n_phi
@@ -118,9 +118,10 @@ def render_image(width: int, height: int, cam_pos: List[float], fov: float, step
                  disk_tilt: float = 0.0, lens_flare: bool = False, anti_alias: str = "disabled",
                  aa_strength: float = 1.0, disk_rotation_speed: float = 0.1, disk_generation_scale: int = 2,
                  force_regenerate_disk_texture: bool = False, ignore_taichi_cache: bool = False,
-                 gpus: int = 1, disk_model: str = "texture") -> np.ndarray:
+                 gpus: int = 1, disk_model: str = "texture", math: Optional[str] = None) -> np.ndarray:
     """One frame -> (H, W, 3) float32 (render.py:4031-4076).  ``gpus > 1`` tiles the frame in row
-    blocks over that many devices of this node (bhr_group_render)."""
+    blocks over that many devices of this node (bhr_group_render).  ``math``: march arithmetic
+    ("strict" | "hybrid" | "fast"; None = HipRenderer's default, strict)."""
     if gpus > 1:
         from .multigpu import render_image_tiled
         return render_image_tiled(width, height, cam_pos, fov, gpus, step_size=step_size, skybox_path=skybox_path,
@@ -128,10 +129,10 @@ def render_image(width: int, height: int, cam_pos: List[float], fov: float, step
                                   disk_texture_path=disk_texture_path, r_disk_inner=r_disk_inner,
                                   r_disk_outer=r_disk_outer, disk_tilt=disk_tilt, lens_flare=lens_flare,
                                   anti_alias=anti_alias, aa_strength=aa_strength,
-                                  disk_rotation_speed=disk_rotation_speed, disk_model=disk_model)
+                                  disk_rotation_speed=disk_rotation_speed, disk_model=disk_model, math=math)
     renderer, use_lifecycle, n_r, n_phi = make_renderer(
         width, height, cam_pos, fov, step_size, skybox_path, n_stars, tex_w, tex_h, r_max, disk_texture_path,
-        r_disk_inner, r_disk_outer, disk_tilt, lens_flare, anti_alias, aa_strength, disk_rotation_speed)
+        r_disk_inner, r_disk_outer, disk_tilt, lens_flare, anti_alias, aa_strength, disk_rotation_speed, math=math)
     if use_analytic_disk(renderer, disk_model):
         pass
     elif use_lifecycle:

@@ -216,6 +216,7 @@ def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devi
     profile of a probe frame (rows through the shadow and the photon ring take more steps) instead of evenly."""
     from .drivers import make_renderer, init_lifecycle_system, advance_lifecycle_frame, use_analytic_disk
     disk_model = kw.pop("disk_model", "texture")
+    math = kw.pop("math", None)
     if devices is None and os.environ.get("BHR_TILE_DEVICES"):     # e.g. "0,0": rehearse two tiles on one card
         devices = [int(d) for d in os.environ["BHR_TILE_DEVICES"].split(",")]
     devices = list(range(gpus)) if devices is None else list(devices)
@@ -228,7 +229,7 @@ def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devi
     tiles = []
     for k, rows in enumerate(blocks):
         r, use_lifecycle, n_r, n_phi = make_renderer(width, height, cam_pos, fov, device_index=devices[k],
-                                                     rows=rows, lens_flare=False, **kw)
+                                                     rows=rows, lens_flare=False, math=math, **kw)
         if use_analytic_disk(r, disk_model):
             pass
         elif use_lifecycle:
