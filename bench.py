@@ -193,7 +193,7 @@ def tile_leg_per_rank(wl, rank, world, local_rank, dist, frames, math=None, warm
         tile.close()
 
 
-def tile_tail_leg(wl, n_tiles=8, math=None, reps=8, verbose=False, schedules=("pipelined",), gathers=("peer_u8",)):
+def tile_tail_leg(wl, n_tiles=8, math=None, reps=8, verbose=False, schedules=("serial", "pipelined"), gathers=("peer_u8",)):
     """What ONE GPU can show of the N-GPU row-block leg: the frame of ``wl`` is cut into ``n_tiles`` cost-balanced row
     blocks, all on this device; after one full render every tile in turn is rendered ALONE (the other tiles keep their
     buffers: bhr_group_render_subset) and timed end to end -- first march launch .. its rows landed in the gather buffer
@@ -253,6 +253,10 @@ def tile_tail_leg(wl, n_tiles=8, math=None, reps=8, verbose=False, schedules=("p
         out["tile_march_alone_ms"] = slow["march_alone_ms"]
         out["tile_tail_ms"] = slow[key] - slow["march_alone_ms"]
         out["tile_tail_frac"] = out["tile_tail_ms"] / slow[key]
+        # what the copies of one tile would take on a 153 GB/s xGMI link (on this device they are HBM to HBM)
+        W, R = wl["width"], int(wl["width"] * 0.02)
+        rows = max(b[1] - b[0] for b in blocks)
+        out["xgmi_copy_ms"] = {"halo_pull": 3 * R * W * 4 / 153e9 * 1e3, "u8_rows": rows * W * 3 / 153e9 * 1e3, "f32_rows": rows * W * 12 / 153e9 * 1e3}
         out["scene"] = note
         return out
     finally:
@@ -260,7 +264,7 @@ def tile_tail_leg(wl, n_tiles=8, math=None, reps=8, verbose=False, schedules=("p
             t.close()
 
 
-def video_leg(n_frames):
+def video_leg(n_frames, math=None):
     """BASELINE.json configs[4] on this GPU: drivers.render_video at fhd (orbit camera, populations ticking, texture
     regenerated every frame, PNG frames encoded on the device and written to a temporary directory).  Informational:
     reported beside the headline, never as `value`."""
@@ -268,7 +272,7 @@ def video_leg(n_frames):
     from bhr_amd import drivers
     tmp = tempfile.mkdtemp(prefix="bhr_bench_video_")
     try:
-        r, _, _, _ = drivers.make_renderer(1920, 1080, [6, 0, 0.5], 90, n_stars=6000)
+        r, _, _, _ = drivers.make_renderer(1920, 1080, [6, 0, 0.5], 90, n_stars=6000, math=math)
         t0 = time.perf_counter()
         drivers.render_video(r, 1920, 1080, n_frames=n_frames, fps=30, output_path=os.path.join(tmp, "v.mp4"), fov=90,
                              static_cam_pos=[6, 0, 0.5], orbit=True, assemble=False, video_stream="off")
@@ -277,7 +281,8 @@ def video_leg(n_frames):
         size = sum(os.path.getsize(os.path.join(drivers._frames_dir(os.path.join(tmp, "v.mp4")), f)) for f in files)
         r.close()
         return {"fps": n_frames / dt, "frames": n_frames, "png_files": len(files), "mb_per_frame": size / max(len(files), 1) / 1e6,
-                "png_encoder": "device", "what": "render_video at 1920x1080: lifecycle init + every frame's populations, "
+                "png_encoder": "device", "march_math": r.math if hasattr(r, "math") else math,
+                "what": "render_video at 1920x1080: lifecycle init + every frame's populations, "
                 "background / entity / compose passes, march, bloom, PNG file on disk"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -465,8 +470,9 @@ def main():
         if os.path.isfile(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(args.workload)
-                traffic_source = tj.get("source")
+                key = f"{args.workload}/{renderer.math}"
+                traffic = tj.get(key, tj.get(args.workload) if renderer.math == "strict" else None)
+                traffic_source = (tj.get("source", "") + f"; key {key}: " + json.dumps(tj.get(f"_{key}_detail", tj.get(f"_{args.workload}_detail")))) if traffic else None
             except Exception:
                 traffic = None
         valu_tflops = MARCH_FLOP_PER_RAY_STEP * k_steps / (march_ms * 1e-3) / 1e12
@@ -518,21 +524,28 @@ def main():
             # what ONE GPU can show of the 8-GPU leg: one tile of eight, alone on the device, timed end to end
             if world == 1 and "ms_per_frame" in tile and args.tile_tail_tiles > 1 and not args.no_other_math:
                 try:
-                    tt = tile_tail_leg(WORKLOADS[args.tile_workload], args.tile_tail_tiles, math=args.math, reps=6)
-                    tile["one_tile_alone"] = {k: tt[k] for k in ("workload", "schedule", "gather", "slowest_tile", "tile_ms", "tile_march_alone_ms",
-                                                                 "tile_tail_ms", "tile_tail_frac", "row_blocks")}
-                    tile["one_tile_alone"]["per_tile_ms"] = [round(r[f"e2e_ms_{tt['schedule']}_{tt['gather']}"], 3) for r in tt["per_tile"]]
-                    tile["one_tile_alone"]["per_tile_march_alone_ms"] = [round(r["march_alone_ms"], 3) for r in tt["per_tile"]]
+                    nt = args.tile_tail_tiles
+                    tt = tile_tail_leg(WORKLOADS[args.tile_workload], nt, math=args.math, reps=6)
+                    per = {sch: [round(r[f"e2e_ms_{sch}_peer_u8"], 3) for r in tt["per_tile"]] for sch in ("serial", "pipelined")}
+                    copies = tt["xgmi_copy_ms"]["halo_pull"] + tt["xgmi_copy_ms"]["u8_rows"]
+                    tile["one_tile_alone"] = {"workload": tt["workload"], "row_blocks": tt["row_blocks"], "per_tile_ms": per,
+                                              "per_tile_march_alone_ms": [round(r["march_alone_ms"], 3) for r in tt["per_tile"]],
+                                              "slowest_tile": tt["slowest_tile"], "tile_ms": tt["tile_ms"], "tile_march_alone_ms": tt["tile_march_alone_ms"],
+                                              "tile_tail_ms": tt["tile_tail_ms"], "tile_tail_frac": tt["tile_tail_frac"], "schedule": tt["schedule"],
+                                              "xgmi_copy_ms": tt["xgmi_copy_ms"]}
                     tile["tile_tail_ms"] = tt["tile_tail_ms"]
-                    tile["predicted_efficiency_at_%d_gpus" % args.tile_tail_tiles] = tile["ms_per_frame"] / (args.tile_tail_tiles * tt["tile_ms"])
-                    tile["prediction_note"] = ("one-GPU frame time / (tiles x slowest tile alone, first march launch .. rows landed); copies "
-                                               "stay on this device, the 14 MB halo pull and 12 MB u8 push of an 8k tile would take ~0.09 / ~0.08 ms "
-                                               "on a 153 GB/s xGMI link, under the march / the next chunk's V pass")
+                    # serial schedule: the copies follow the V pass, add their xGMI time; pipelined: they hide under the V pass
+                    tile[f"predicted_efficiency_at_{nt}_gpus"] = {
+                        "serial_schedule_plus_xgmi_copies": tile["ms_per_frame"] / (nt * (max(per["serial"]) + copies)),
+                        "pipelined_schedule": tile["ms_per_frame"] / (nt * max(per["pipelined"])),
+                        "note": "one-GPU frame time / (tiles x slowest tile alone, first march launch .. rows landed in the frame buffer); measured on ONE "
+                                "device, where a tile's copies are HBM to HBM: the serial figure adds what the halo pull and the u8 rows would take on a "
+                                "153 GB/s link, the pipelined schedule overlaps them with the V pass"}
                 except Exception as e:
                     tile["one_tile_alone"] = {"error": f"{type(e).__name__}: {e}"}
         if args.video_frames > 0 and world == 1 and not args.no_other_math:
             try:
-                out["video_loop"] = video_leg(args.video_frames)
+                out["video_loop"] = video_leg(args.video_frames, math=args.math)
             except Exception as e:      # the headline stands on its own
                 out["video_loop"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:

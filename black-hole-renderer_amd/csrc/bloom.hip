@@ -230,15 +230,24 @@ __global__ __launch_bounds__(256) void bloom_v_kernel(const float *__restrict__ 
 // conv4 above serves one group of 4 outputs per call, so a thread with G groups walks the weight table G times and
 // every 16 FMAs wait for their own scalar load.  conv4g keeps NG accumulator groups live and feeds all of them from one
 // fetch: 16 NG FMAs per scalar load, NG independent dependency chains per lane.
-template <int NG>
+// WLDS: the weight table lives in LDS (`wx` points into it, 16-byte aligned) and each tap block's weights arrive as two
+// broadcast ds_read_b128 in VGPRs; otherwise they are scalar loads used as SGPR operands.  v_fmac_f32 with an SGPR
+// operand issues at HALF the rate of the all-VGPR form on gfx950 (tools/ubench_fmac.hip) -- the round-2 kernels were
+// VALU-busy ~100 % of the time at 4 cycles per FMA.
+template <int NG, bool WLDS = false>
 __device__ __forceinline__ void conv4g(const float *__restrict__ win, int gstride, int M, const float *__restrict__ wx,
                                        float (&acc)[NG][4]) {
 #pragma unroll 2
     for (int m = 0; m < M; ++m) {
         const float *__restrict__ wp = wx + 4 * m;
-        float w[7];
+        float w[8];
+        if (WLDS) {
+            const float4 wa = *reinterpret_cast<const float4 *>(wp), wb = *reinterpret_cast<const float4 *>(wp + 4);
+            w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w; w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
+        } else {
 #pragma unroll
-        for (int t = 0; t < 7; ++t) w[t] = wp[t];
+            for (int t = 0; t < 7; ++t) w[t] = wp[t];
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const float4 v = *reinterpret_cast<const float4 *>(win + g * gstride + 4 * m);
@@ -251,7 +260,7 @@ __device__ __forceinline__ void conv4g(const float *__restrict__ win, int gstrid
 }
 
 // H pass, NG groups per thread 1024 pixels apart: a block covers 1024 NG pixels of one row.
-template <int NG>
+template <int NG, bool WLDS = false>
 __global__ __launch_bounds__(256) void bloom_h2_kernel(const float *__restrict__ disk, float *__restrict__ hblur,
                                                        const float *__restrict__ wext, const float *__restrict__ wsum_h,
                                                        int W, int rows, int R, int row_begin) {
@@ -259,6 +268,9 @@ __global__ __launch_bounds__(256) void bloom_h2_kernel(const float *__restrict__
     constexpr int PIX = HB_PIX * NG;
     const int R4 = (R + 3) & ~3;
     const int span = PIX + 2 * R4 + 4;
+    float *wl = lds + 3 * span;                    // WLDS: the three unfolded weight tables, 2 R4 + 8 floats each
+    if (WLDS)
+        for (int k = threadIdx.x; k < 3 * (2 * R4 + 8); k += 256) wl[k] = wext[k];
     const int x0 = blockIdx.x * PIX;
     const int row = blockIdx.y + row_begin;
     const int tid = threadIdx.x;
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void bloom_h2_kernel(const float *__restrict__
         float acc[NG][4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) acc[g][0] = acc[g][1] = acc[g][2] = acc[g][3] = 0.0f;
-        conv4g<NG>(lds + c * span + 4 * tid, HB_PIX, M, wext + c * xstride, acc);
+        conv4g<NG, WLDS>(lds + c * span + 4 * tid, HB_PIX, M, (WLDS ? wl : wext) + c * xstride, acc);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int x = x0 + g * HB_PIX + 4 * tid;
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(256) void bloom_h2_kernel(const float *__restrict__
 
 // V pass, COLS columns x (256 / COLS) row lanes x G groups x 4 rows per block.  COLS = 16 halves the LDS tile of the
 // 32-column kernel (the 2 R halo rows dominate it: 73 KB at 8k, two blocks per CU), so four blocks fit a CU.
-template <int COLS, int G>
+template <int COLS, int G, bool WLDS = false>
 __global__ __launch_bounds__(256) void bloom_v2_kernel(const float *__restrict__ hblur, const float *__restrict__ bg,
                                                        const float *__restrict__ disk, float *__restrict__ blur_out,
                                                        float *__restrict__ final_out, const float *__restrict__ wext,
@@ -319,6 +331,9 @@ __global__ __launch_bounds__(256) void bloom_v2_kernel(const float *__restrict__
     const int xstride = 2 * R4 + 8;
     const int tile_rows = VROWS + 2 * R4 + 4;
     const int M = (2 * R4) / 4 + 1;
+    float *wl = lds + COLS * S;                    // WLDS: the weight tables behind the tile
+    if (WLDS && with_bloom)
+        for (int k = threadIdx.x; k < 3 * xstride; k += 256) wl[k] = wext[k];
 
     float res[3][G][4];
 #pragma unroll
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(256) void bloom_v2_kernel(const float *__restrict__
             }
             __syncthreads();
             // group g of this lane = rows 4 (lane_g + LG g) .. + 3 of the tile
-            conv4g<G>(lds + col * S + 4 * lane_g, 4 * LG, M, wext + c * xstride, res[c]);
+            conv4g<G, WLDS>(lds + col * S + 4 * lane_g, 4 * LG, M, (WLDS ? wl : wext) + c * xstride, res[c]);
         }
     }
     if (x >= W) return;
@@ -377,32 +392,259 @@ __global__ __launch_bounds__(256) void bloom_v2_kernel(const float *__restrict__
     }
 }
 
+// ---- V pass on the matrix cores -------------------------------------------------------------------------------------
+// The vertical blur of a 32-column strip is a banded Toeplitz product  out(y, x) = sum_i T(y, i) in(i, x),  T(y, i) =
+// w[|i - y|].  v_mfma_f32_32x32x2_f32 takes exactly that shape: D(32 y x 32 x) += A(32 y x 2 i) B(2 i x 32 x), exact f32
+// (bit for bit a k-ordered fmaf chain, MI355X_MICROARCH.md) at the f32 vector peak -- but with operands that cost almost
+// nothing to fetch, where the VALU kernels above are bound by what feeds their FMAs (SGPR-operand FMAs issue at half
+// rate, VGPR weights come through LDS, tools/ubench_fmac.hip):
+//   B  lane l holds in(i0 + (l >> 5), x0 + (l & 31)): two 128-byte row segments of the planar H-blur buffer, straight
+//      from global memory (L2-resident: every input row is read by (32 T + 2 R) / 32 T row groups), no LDS staging;
+//   A  lane l holds w[|i0 + (l >> 5) - y - (l & 31)|]: one ds_read_b32 from a zero-padded table of 2 R + 64 T + 44 weights.
+// A wave owns T stacked 32-row tiles of one strip for all three channels (48 T accumulator registers), walks the input
+// rows in pairs, and each pair feeds the tiles whose band it touches.  Accumulation order per output = ascending input
+// row, whatever the tiling: row blocks, chunks and whole frames give the same bits.  No dense GEMM is invented here --
+// the 91 % of the issued multiply-adds that fall inside the band are the convolution's own.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 48 T accumulator registers (AGPRs) + ~30 for the loop; the epilogue is held to what is left at 4 (T <= 2) waves per SIMD
+template <int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T == 1 ? 4 : T == 2 ? 3 : 2, T == 1 ? 4 : T == 2 ? 3 : 2))) void bloom_v_mfma_kernel(const float *__restrict__ hblur, const float *__restrict__ bg,
+                                                           const float *__restrict__ disk, float *__restrict__ blur_out,
+                                                           float *__restrict__ final_out, const float *__restrict__ wtab,
+                                                           const float *__restrict__ wsum_v, int W, int H, int row0, int rows,
+                                                           int R, int with_bloom, unsigned long long *__restrict__ zero_cell,
+                                                           int row_begin, int row_end, uint8_t *__restrict__ u8_out) {
+    if (zero_cell && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < BHR_STEP_LANES)
+        zero_cell[(size_t)threadIdx.x * BHR_STEP_STRIDE] = 0ull;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // wl[3][NW]: w[|d|] at index d + OFF, zero beyond R
+    const int OFF = R + 32 * T + 2, NW = 2 * R + 64 * T + 44;     // every (pair, tile) offset lands inside: no band test in the loop
+    if (with_bloom) {
+        const int wstride = R + 1 + WPAD;
+        for (int k = threadIdx.x; k < 3 * NW; k += 256) {
+            const int c = k / NW, d = k - c * NW - OFF, ad = d < 0 ? -d : d;
+            lds[k] = ad <= R ? wtab[c * wstride + ad] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xs = (blockIdx.x * 4 + wave) * 32;                  // this wave's column strip
+    const int y0 = row_begin + blockIdx.y * (32 * T);             // local row of its first output
+    if (xs >= W) return;
+    const int x = xs + (lane & 31), kh = lane >> 5;
+    const bool x_ok = x < W;
+
+    f32x16 acc[3][T];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.0f;
+
+    if (with_bloom) {
+        const size_t plane = (size_t)(rows + 2 * R) * W;
+        const int Rp = R + (R & 1);
+        const int i_first = y0 - Rp, i_last = y0 + 32 * T - 1 + R;          // input rows (local), walked in pairs
+        const int lane_off = OFF + kh - (lane & 31);
+        auto load_b = [&](int i0, float (&b)[3]) {
+            const int yl = i0 + kh, yg = yl + row0;
+            const bool ok = x_ok && yg >= 0 && yg < H && yl >= -R && yl < rows + R;   // outside the image: a skipped tap
+            const size_t o = ok ? (size_t)(yl + R) * W + x : 0;
+            b[0] = ok ? hblur[o] : 0.0f;
+            b[1] = ok ? hblur[plane + o] : 0.0f;
+            b[2] = ok ? hblur[2 * plane + o] : 0.0f;
+        };
+        // PF row pairs per group: the next group's 3 PF loads are in flight under this group's 3 T PF MFMAs (64 cycles each)
+        // -- an L2 round trip is several hundred ns, one pair's MFMAs cover 160
+        constexpr int PF = 4;
+        float b[PF][3], bn[PF][3];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) load_b(i_first + 2 * q, b[q]);
+        for (int i0 = i_first; i0 <= i_last; i0 += 2 * PF) {
+#pragma unroll
+            for (int q = 0; q < PF; ++q) load_b(i0 + 2 * (PF + q), bn[q]);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    // a pair outside tile t's band (or past the last input row) reads zeros from the padded table: cheaper
+                    // than a branch, whose merge copies the 48 T accumulator registers
+                    const int idx = lane_off + (i0 + 2 * q - y0 - 32 * t);
+                    const float a0 = lds[idx], a1 = lds[NW + idx], a2 = lds[2 * NW + idx];
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[q][0], acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[q][1], acc[1][t], 0, 0, 0);
+                    acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b[q][2], acc[2][t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PF; ++q) { b[q][0] = bn[q][0]; b[q][1] = bn[q][1]; b[q][2] = bn[q][2]; }
+        }
+    }
+    if (!x_ok) return;
+    // D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int yl = y0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (yl >= row_end) continue;
+            const int yg = yl + row0;
+            float b0 = 0, b1 = 0, b2 = 0;
+            if (with_bloom) {
+                b0 = acc[0][t][r] / wsum_v[yg];
+                b1 = acc[1][t][r] / wsum_v[H + yg];
+                b2 = acc[2][t][r] / wsum_v[2 * H + yg];
+            }
+            const size_t o = ((size_t)yl * W + x) * 3;
+            blur_out[o + 0] = b0;
+            blur_out[o + 1] = b1;
+            blur_out[o + 2] = b2;
+            const float f0 = fminf(fmaxf(bg[o + 0] + disk[o + 0] + b0, 0.0f), 1.0f);
+            const float f1 = fminf(fmaxf(bg[o + 1] + disk[o + 1] + b1, 0.0f), 1.0f);
+            const float f2 = fminf(fmaxf(bg[o + 2] + disk[o + 2] + b2, 0.0f), 1.0f);
+            final_out[o + 0] = f0;
+            final_out[o + 1] = f1;
+            final_out[o + 2] = f2;
+            if (u8_out) {
+                u8_out[o + 0] = (uint8_t)(int)(f0 * 255.0f);
+                u8_out[o + 1] = (uint8_t)(int)(f1 * 255.0f);
+                u8_out[o + 2] = (uint8_t)(int)(f2 * 255.0f);
+            }
+        }
+    }
+}
+
+// H pass on the matrix cores: the same product with the roles turned.  D(32 rows y x 32 outputs x) += A(32 y x 2 i) B(2 i x 32 x):
+//   A  lane l holds the INPUT pixel (y0 + (l & 31), i0 + (l >> 5)) -- every lane streams along its own row of the
+//      (rows, W, 3) disk layer, one 12-byte load brings the three channels of a tap;
+//   B  lane l holds w[|i0 + (l >> 5) - x - (l & 31)|] from the zero-padded LDS table.
+// A wave owns T adjacent 32-pixel output tiles of 32 rows; D's column index is the lane, so a store writes 32 consecutive
+// floats of one planar H-blur row.  Ascending input order per output, whatever the tiling.
+template <int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T == 1 ? 4 : T == 2 ? 3 : 2, T == 1 ? 4 : T == 2 ? 3 : 2))) void bloom_h_mfma_kernel(
+    const float *__restrict__ disk, float *__restrict__ hblur, const float *__restrict__ wtab, const float *__restrict__ wsum_h,
+    int W, int rows, int R, int row_begin, int row_end) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int OFF = R + 32 * T + 2, NW = 2 * R + 64 * T + 44;
+    {
+        const int wstride = R + 1 + WPAD;
+        for (int k = threadIdx.x; k < 3 * NW; k += 256) {
+            const int c = k / NW, d = k - c * NW - OFF, ad = d < 0 ? -d : d;
+            lds[k] = ad <= R ? wtab[c * wstride + ad] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = blockIdx.x * (32 * T);                          // first output pixel of the wave's tiles
+    const int y0 = row_begin + (blockIdx.y * 4 + wave) * 32;      // its 32 rows
+    if (y0 >= row_end) return;
+    const int kh = lane >> 5, yl = y0 + (lane & 31);
+    const bool y_ok = yl < row_end;
+    const float *src = disk + (size_t)(y_ok ? yl : y0) * W * 3;
+
+    f32x16 acc[3][T];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.0f;
+
+    const int Rp = R + (R & 1);
+    const int i_first = x0 - Rp, i_last = x0 + 32 * T - 1 + R;
+    const int lane_off = OFF + kh - (lane & 31);
+    auto load_a = [&](int i0, float (&a)[3]) {
+        const int i = i0 + kh;
+        const bool ok = y_ok && i >= 0 && i < W;                 // outside the image: a skipped tap
+        const float *q = src + (size_t)(ok ? i : 0) * 3;
+        a[0] = ok ? q[0] : 0.0f;
+        a[1] = ok ? q[1] : 0.0f;
+        a[2] = ok ? q[2] : 0.0f;
+    };
+    constexpr int PF = 4;
+    float a[PF][3], an[PF][3];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) load_a(i_first + 2 * q, a[q]);
+    for (int i0 = i_first; i0 <= i_last; i0 += 2 * PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) load_a(i0 + 2 * (PF + q), an[q]);
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int idx = lane_off + (i0 + 2 * q - x0 - 32 * t);
+                const float b0 = lds[idx], b1 = lds[NW + idx], b2 = lds[2 * NW + idx];
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][0], b0, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][1], b1, acc[1][t], 0, 0, 0);
+                acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][2], b2, acc[2][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PF; ++q) { a[q][0] = an[q][0]; a[q][1] = an[q][1]; a[q][2] = an[q][2]; }
+    }
+    // D: column = lane & 31 -> output pixel, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> row of the wave's 32
+    const size_t plane = (size_t)(rows + 2 * R) * W;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int x = x0 + 32 * t + (lane & 31);
+        if (x >= W) continue;
+        const float s0 = wsum_h[x], s1 = wsum_h[W + x], s2 = wsum_h[2 * W + x];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (y >= row_end) continue;
+            const size_t o = (size_t)(y + R) * W + x;
+            hblur[o] = acc[0][t][r] / s0;
+            hblur[plane + o] = acc[1][t][r] / s1;
+            hblur[2 * plane + o] = acc[2][t][r] / s2;
+        }
+    }
+}
+
 // V-pass geometry of this context: columns per block, row groups per thread (rows per block = 256 / cols x 4 x groups).
 // BHR_BLOOM_V="<cols>x<groups>" overrides ("32x0": the round-2 kernel with its own table below); BHR_BLOOM_H=<NG>.
 struct VGeom { int cols, groups, v2; };
 // Round-2 table of the 32-column kernel (v2 = 0): G = 1 (32 rows) up to fhd, 4 at 4k, 8 (256 rows) at 8k.
 VGeom v_geometry(int R, int rows) {
-    VGeom g{32, 1, 0};
-    if (R >= 64) g.groups = (R >= 128 && rows > 128) ? 8 : 4;
-    if (const char *e = getenv("BHR_BLOOM_VG")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) g.groups = v; }
+    // default: the matrix-core kernel, one 32-row tile per wave -- 1.03 / 0.190 / 0.041 ms at 8k / 4k / fhd against 1.78 /
+    // 0.247 / 0.040 of the round-2 kernel and 1.21 / 0.193 / 0.041 of the 16-column VALU kernel (tools/exp_bloom.py)
+    VGeom g{128, 1, 2};
     if (const char *e = getenv("BHR_BLOOM_V")) {
-        int c = 0, k = 0;
-        if (sscanf(e, "%dx%d", &c, &k) == 2 && (c == 16 || c == 32) && (k == 0 || k == 1 || k == 2 || k == 4 || k == 8)) {
-            if (k != 0) { g.cols = c; g.groups = k; g.v2 = 1; }
+        if (e[0] != 'm') { g = VGeom{32, 1, 0}; if (R >= 64) g.groups = (R >= 128 && rows > 128) ? 8 : 4; }
+    }
+    if (const char *e = getenv("BHR_BLOOM_VG")) { int v = atoi(e); if (g.v2 == 0 && (v == 1 || v == 2 || v == 4 || v == 8)) g.groups = v; }
+    if (const char *e = getenv("BHR_BLOOM_V")) {
+        if (e[0] == 'm') {                         // "mfma1" / "mfma2" / "mfma4": T stacked 32-row tiles per wave
+            const int t = atoi(e + 4);
+            g.cols = 128; g.groups = (t == 1 || t == 2 || t == 4) ? t : 2; g.v2 = 2;
+            return g;
         }
+        int c = 0, k = 0;
+        // "16x<G>": the 16-column VALU kernel with G row groups per thread; "32x0": the round-2 kernel with its own table
+        if (sscanf(e, "%dx%d", &c, &k) == 2 && c == 16 && (k == 1 || k == 2 || k == 4)) { g.cols = 16; g.groups = k; g.v2 = 1; }
     }
     return g;
 }
-int v_rows_per_block(const VGeom &g) { return 256 / g.cols * 4 * g.groups; }
+int v_rows_per_block(const VGeom &g) { return g.v2 == 2 ? 32 * g.groups : 256 / g.cols * 4 * g.groups; }
 int v_stride(int R, const VGeom &g) {   // LDS column stride: >= tile rows, multiple of 4 with an odd quotient (bank spread)
     const int R4 = (R + 3) & ~3;
     int s = v_rows_per_block(g) + 2 * R4 + 4;
     if (((s >> 2) & 1) == 0) s += 4;
     return s;
 }
+bool weights_in_lds() {
+    if (const char *e = getenv("BHR_BLOOM_W")) return e[0] == 'l';
+    return true;
+}
 int h_groups() {
-    if (const char *e = getenv("BHR_BLOOM_H")) { int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) return v; }
-    return 0;                             // 0: the round-2 kernel
+    if (const char *e = getenv("BHR_BLOOM_H")) {
+        if (e[0] == 'm') { const int t = atoi(e + 4); return 100 + ((t == 1 || t == 2 || t == 4) ? t : 2); }   // "mfma<T>"
+        int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) return v;
+    }
+    // measured at 8k / 4k / fhd (tools/exp_bloom.py, profiles/r03_bloom_variants.md): two groups per thread with the
+    // weights as VGPR operands 0.87 / 0.127 / 0.026 ms; the round-2 kernel 0.97 / 0.146 / 0.030; the MFMA form 0.87 / 0.149 / 0.048
+    return 2;
 }
 
 // kernels that need more than 48 KB of dynamic LDS are told so once
@@ -448,14 +690,29 @@ int32_t bhr_launch_bloom_h_rows(bhr_ctx *ctx, int32_t r0, int32_t r1) {
     if (r0 == r1) return BHR_OK;
     const int R4 = (R + 3) & ~3;
     const int ng = h_groups();
+    if (ng >= 100) {
+        const int T = ng - 100;
+        dim3 mgrid((W + 32 * T - 1) / (32 * T), (r1 - r0 + 127) / 128), mblock(256);
+        const size_t mlds = (size_t)3 * (2 * R + 64 * T + 44) * sizeof(float);
+#define BHR_HM_ARGS mgrid, mblock, mlds, ctx->stream, ctx->d_disk, ctx->d_hblur, ctx->d_wtab, ctx->d_wsum_h, W, ctx->rows, R, r0, r1
+        if (T == 1) hipLaunchKernelGGL(bloom_h_mfma_kernel<1>, BHR_HM_ARGS);
+        else if (T == 4) hipLaunchKernelGGL(bloom_h_mfma_kernel<4>, BHR_HM_ARGS);
+        else hipLaunchKernelGGL(bloom_h_mfma_kernel<2>, BHR_HM_ARGS);
+#undef BHR_HM_ARGS
+        BHR_HIP(hipGetLastError());
+        return BHR_OK;
+    }
     const int pix = HB_PIX * (ng ? ng : 1);
     dim3 grid((W + pix - 1) / pix, r1 - r0), block(256);
-    const size_t lds = (size_t)3 * (pix + 2 * R4 + 4) * sizeof(float);
+    const bool wlds = weights_in_lds() && ng != 0;
+    const size_t lds = ((size_t)3 * (pix + 2 * R4 + 4) + (wlds ? 3 * (2 * R4 + 8) : 0)) * sizeof(float);
 #define BHR_H_ARGS grid, block, lds, ctx->stream, ctx->d_disk, ctx->d_hblur, ctx->d_wext, ctx->d_wsum_h, W, ctx->rows, R, r0
-    if (ng == 0) { hipLaunchKernelGGL(bloom_h_kernel, BHR_H_ARGS); }
-    else if (ng == 1) { hipLaunchKernelGGL(bloom_h2_kernel<1>, BHR_H_ARGS); }
-    else if (ng == 2) { hipLaunchKernelGGL(bloom_h2_kernel<2>, BHR_H_ARGS); }
-    else { BHR_TRY(allow_lds((const void *)bloom_h2_kernel<4>, lds)); hipLaunchKernelGGL(bloom_h2_kernel<4>, BHR_H_ARGS); }
+#define BHR_H_LAUNCH(KERNEL) do { BHR_TRY(allow_lds((const void *)KERNEL, lds)); hipLaunchKernelGGL(KERNEL, BHR_H_ARGS); } while (0)
+    if (ng == 0) BHR_H_LAUNCH(bloom_h_kernel);
+    else if (ng == 1) { if (wlds) BHR_H_LAUNCH((bloom_h2_kernel<1, true>)); else BHR_H_LAUNCH((bloom_h2_kernel<1, false>)); }
+    else if (ng == 2) { if (wlds) BHR_H_LAUNCH((bloom_h2_kernel<2, true>)); else BHR_H_LAUNCH((bloom_h2_kernel<2, false>)); }
+    else { if (wlds) BHR_H_LAUNCH((bloom_h2_kernel<4, true>)); else BHR_H_LAUNCH((bloom_h2_kernel<4, false>)); }
+#undef BHR_H_LAUNCH
 #undef BHR_H_ARGS
     BHR_HIP(hipGetLastError());
     return BHR_OK;
@@ -473,9 +730,24 @@ int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, in
     if (r0 < 0 || r1 > ctx->rows || r0 > r1) return bhr_fail(BHR_ERR_INVALID, "bloom V: rows [%d,%d) of %d", r0, r1, ctx->rows);
     if (r0 == r1) return BHR_OK;
     const VGeom g = v_geometry(R, ctx->rows);
+    if (g.v2 == 2) {
+        const int vb = 32 * g.groups;
+        dim3 mgrid((W + 127) / 128, (r1 - r0 + vb - 1) / vb), mblock(256);
+        const size_t mlds = with_bloom ? (size_t)3 * (2 * R + 64 * g.groups + 44) * sizeof(float) : 0;
+#define BHR_VM_ARGS mgrid, mblock, mlds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_wtab, \
+                    ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, with_bloom, ctx->v_zero_cell, r0, r1, u8_out
+        if (g.groups == 1) hipLaunchKernelGGL(bloom_v_mfma_kernel<1>, BHR_VM_ARGS);
+        else if (g.groups == 4) hipLaunchKernelGGL(bloom_v_mfma_kernel<4>, BHR_VM_ARGS);
+        else hipLaunchKernelGGL(bloom_v_mfma_kernel<2>, BHR_VM_ARGS);
+#undef BHR_VM_ARGS
+        BHR_HIP(hipGetLastError());
+        return BHR_OK;
+    }
     const int S = v_stride(R, g), vb_rows = v_rows_per_block(g);
     dim3 grid((W + g.cols - 1) / g.cols, (r1 - r0 + vb_rows - 1) / vb_rows), block(256);
-    const size_t lds = with_bloom ? (size_t)g.cols * S * sizeof(float) : 0;
+    const bool wlds = weights_in_lds() && g.v2;
+    const int R4v = (R + 3) & ~3;
+    const size_t lds = with_bloom ? ((size_t)g.cols * S + (wlds ? 3 * (2 * R4v + 8) : 0)) * sizeof(float) : 0;
 #define BHR_V_ARGS grid, block, lds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_wext, \
                    ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, S, with_bloom, ctx->v_zero_cell, r0, r1, u8_out
 #define BHR_V_LAUNCH(KERNEL) do { BHR_TRY(allow_lds((const void *)KERNEL, lds)); hipLaunchKernelGGL(KERNEL, BHR_V_ARGS); } while (0)
@@ -484,16 +756,12 @@ int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, in
         else if (g.groups == 4) BHR_V_LAUNCH(bloom_v_kernel<4>);
         else if (g.groups == 1) BHR_V_LAUNCH(bloom_v_kernel<1>);
         else BHR_V_LAUNCH(bloom_v_kernel<2>);
-    } else if (g.cols == 32) {
-        if (g.groups == 8) BHR_V_LAUNCH((bloom_v2_kernel<32, 8>));
-        else if (g.groups == 4) BHR_V_LAUNCH((bloom_v2_kernel<32, 4>));
-        else if (g.groups == 1) BHR_V_LAUNCH((bloom_v2_kernel<32, 1>));
-        else BHR_V_LAUNCH((bloom_v2_kernel<32, 2>));
     } else {
-        if (g.groups == 8) BHR_V_LAUNCH((bloom_v2_kernel<16, 8>));
-        else if (g.groups == 4) BHR_V_LAUNCH((bloom_v2_kernel<16, 4>));
-        else if (g.groups == 1) BHR_V_LAUNCH((bloom_v2_kernel<16, 1>));
-        else BHR_V_LAUNCH((bloom_v2_kernel<16, 2>));
+#define BHR_V_PICK(C, K) do { if (wlds) BHR_V_LAUNCH((bloom_v2_kernel<C, K, true>)); else BHR_V_LAUNCH((bloom_v2_kernel<C, K, false>)); } while (0)
+        if (g.groups == 4) BHR_V_PICK(16, 4);
+        else if (g.groups == 1) BHR_V_PICK(16, 1);
+        else BHR_V_PICK(16, 2);
+#undef BHR_V_PICK
     }
 #undef BHR_V_LAUNCH
 #undef BHR_V_ARGS

@@ -7,15 +7,19 @@
 //  * serial (BHR_GROUP_SERIAL, round 1-2): per tile march -> H pass -> halo pull -> V pass -> gather, each step behind
 //    the previous one on the tile's stream.  At 8 tiles of an 8k frame the steps after the march (H 0.12, halo 0.1,
 //    V 0.34, f32 gather 0.33 ms) are a 0.9 ms tail behind a 3.0 ms march.
-//  * pipelined (default): per tile three streams.
-//      march stream  the march in TWO launches over complementary tile lists: the halo bands (the R rows next to each
-//                    neighbour) first, the rows between them second;
-//      post stream   H pass of the bands as soon as the first launch is done -> `halo_ready`; H pass of the rest after
-//                    the second; V pass + combine in row chunks, each chunk's quantised bytes written by the V kernel's
-//                    epilogue (BHR_GATHER_U8);
-//      copy stream   pulls the neighbours' halo rows behind THEIR `halo_ready` -- under the march of the middle rows --
-//                    and pushes every finished chunk into the frame buffer on tile 0's device while the next chunk's V
+//  * pipelined: per tile three streams.
+//      tile stream   march -> H pass -> `halo_ready` -> V pass + combine in row chunks: the rows at least R away from a
+//                    neighbouring tile FIRST (they need no halo), the rows next to the edges once the halo has arrived;
+//                    each chunk's quantised bytes are written by the V kernel's epilogue (BHR_GATHER_U8);
+//      copy stream   pulls the neighbours' halo rows behind THEIR `halo_ready`, under the V pass of the middle rows;
+//      push stream   pushes every finished chunk into the frame buffer on tile 0's device while the next chunk's V
 //                    kernel runs.  u8 rows: 12.4 MB per 8k tile instead of 49.8 MB of f32.
+//    Default where the tiles sit on DISTINCT devices (the copies cross xGMI: ~0.09 ms halo + ~0.08 ms u8 rows of an 8k
+//    tile); tiles sharing one device default to the serial schedule -- their copies are HBM to HBM and every cross-stream
+//    hand-over costs more than it hides (tools/exp_tile_tail.py).  BHR_GROUP_SCHEDULE / BHR_GROUP_SERIAL override.
+//    Tried and removed: marching the halo bands in a launch of their own so that the pull starts under the march of the
+//    middle rows, H / V on a high-priority stream of their own -- the second launch's ragged start and the extra
+//    hand-overs cost an 8k tile 0.2-0.5 ms against the 0.09 ms they hide.
 //    The lens flare needs the frame's three sums (a host read-back on tile 0), so with BHR_LENS_FLARE the chunks stay on
 //    the device until the flare has been applied; march / H / halo / V are pipelined all the same.
 //
@@ -37,13 +41,8 @@ namespace {
 constexpr int PIPE_MAX_CHUNKS = 16;
 
 struct TilePipe {
-    hipStream_t post, copy;
-    hipEvent_t march_a, march_b, halo_ready, h_all, halo_in, v_done[PIPE_MAX_CHUNKS], landed, post_done, glow_ready;
-    int32_t *d_band, *h_band;     // halo-band tiles first, then the rest; launch order kept inside both
-    int32_t n_band, n_rest;
-    int32_t band_top;             // local rows [0, band_top) form the upper halo band (0: none)
-    int32_t band_bot;             // local rows [band_bot, rows) the lower one (rows: none)
-    int32_t key;                  // 4 | has_up | has_down << 1 once the lists are built
+    hipStream_t copy, push;       // halo pulls; pushes of finished row chunks
+    hipEvent_t halo_ready, halo_in, v_done[PIPE_MAX_CHUNKS], landed;
     // one-process-per-tile variant (bhr_tile_connect): the neighbours' H-blur planes and tile 0's frame buffers, opened
     // from their IPC handles; counters in host shared memory for the hand-shakes
     int32_t linked, rank, world;
@@ -67,51 +66,43 @@ int32_t dev_alloc(T **p, size_t count) {
     return BHR_OK;
 }
 
-int32_t ensure_pipe(bhr_ctx *ctx, bool has_up, bool has_down) {
-    TilePipe *p = (TilePipe *)ctx->pipe;
-    if (!p) {
-        p = new TilePipe();
-        memset(p, 0, sizeof(*p));
-        ctx->pipe = p;
-        int lo = 0, hi = 0;
-        BHR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));       // hi = greatest priority (numerically lowest)
-        // the post and copy streams carry short, latency-critical work next to a long march: highest priority
-        const char *e = getenv("BHR_PIPE_PRIORITY");
-        const int prio = (e && atoi(e) == 0) ? lo : hi;
-        BHR_HIP(hipStreamCreateWithPriority(&p->post, hipStreamNonBlocking, prio));
-        BHR_HIP(hipStreamCreateWithPriority(&p->copy, hipStreamNonBlocking, prio));
-        hipEvent_t *evs[] = {&p->march_a, &p->march_b, &p->halo_ready, &p->h_all, &p->halo_in, &p->landed, &p->post_done, &p->glow_ready};
-        for (hipEvent_t *ev : evs) BHR_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-        for (auto &ev : p->v_done) BHR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
-    const int key = 4 | (has_up ? 1 : 0) | (has_down ? 2 : 0);
-    if (p->key == key) return BHR_OK;
-    BHR_TRY(bhr_ensure_tile_order(ctx));
-    const int rows = ctx->rows, R = ctx->bloom_R, n_tiles = ctx->tile_order_n, tiles_x = (ctx->cfg.width + 7) / 8;
-    const int band = ((R + 7) / 8) * 8;                           // whole 8-row tile rows that cover R rows
-    p->band_top = has_up ? (band < rows ? band : rows) : 0;
-    int bot = has_down ? ((rows - R) > 0 ? ((rows - R) / 8) * 8 : 0) : rows;
-    if (bot < p->band_top) bot = p->band_top;
-    p->band_bot = bot;
-    if (!p->h_band) {
-        p->h_band = (int32_t *)malloc((size_t)n_tiles * sizeof(int32_t));
-        if (!p->h_band) return bhr_fail(BHR_ERR_NOMEM, "tile pipe: out of host memory");
-        BHR_TRY(dev_alloc(&p->d_band, (size_t)n_tiles));
-    }
-    int n = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int k = 0; k < n_tiles; ++k) {
-            const int t = ctx->h_tile_order[k], y = (t / tiles_x) * 8;
-            const bool in_band = y < p->band_top || y >= p->band_bot;
-            if (in_band == (pass == 0)) p->h_band[n++] = t;
-        }
-        if (pass == 0) p->n_band = n;
-    }
-    p->n_rest = n_tiles - p->n_band;
-    BHR_HIP(hipMemcpyAsync(p->d_band, p->h_band, (size_t)n_tiles * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    BHR_HIP(hipStreamSynchronize(ctx->stream));
-    p->key = key;
+int32_t ensure_pipe(bhr_ctx *ctx) {
+    if (ctx->pipe) return BHR_OK;
+    TilePipe *p = new TilePipe();
+    memset(p, 0, sizeof(*p));
+    ctx->pipe = p;
+    BHR_HIP(hipStreamCreateWithFlags(&p->copy, hipStreamNonBlocking));
+    BHR_HIP(hipStreamCreateWithFlags(&p->push, hipStreamNonBlocking));
+    hipEvent_t *evs[] = {&p->halo_ready, &p->halo_in, &p->landed};
+    for (hipEvent_t *ev : evs) BHR_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    for (auto &ev : p->v_done) BHR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     return BHR_OK;
+}
+
+// Row chunks of a tile's V pass, in launch order.  Rows at least R away from a neighbouring tile need no halo rows: they
+// go first, under the halo pull; the rows next to the tile's edges follow once the halo has arrived.  Every chunk is
+// pushed to tile 0 while the next one's V kernel runs.  Chunk boundaries fall on multiples of the V kernel's block height.
+struct Chunk { int r0, r1, needs_halo; };
+int plan_chunks(const bhr_ctx *c, bool has_up, bool has_down, int vb, Chunk (&out)[PIPE_MAX_CHUNKS]) {
+    const int rows = c->rows, R = c->bloom_R;
+    int want = 3;
+    if (const char *e = getenv("BHR_TILE_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= PIPE_MAX_CHUNKS - 2) want = v; }
+    int n = 0;
+    auto add = [&](int r0, int r1, int halo, int pieces) {
+        if (r1 <= r0) return;
+        int step = ((r1 - r0 + pieces - 1) / pieces + vb - 1) / vb * vb;
+        for (int r = r0; r < r1 && n < PIPE_MAX_CHUNKS; r += step) out[n++] = Chunk{r, r + step < r1 ? r + step : r1, halo};
+    };
+    int m0 = has_up ? (R + vb - 1) / vb * vb : 0;
+    if (m0 > rows) m0 = rows;
+    int m1 = has_down ? m0 + ((rows - R - m0) > 0 ? (rows - R - m0) / vb * vb : 0) : rows;
+    if (m1 > rows) m1 = rows;
+    if (m1 < m0) m1 = m0;
+    if (!has_up && !has_down) { add(0, rows, 0, want); return n; }
+    add(m0, m1, 0, want > 2 ? want - 2 : 1);       // the middle: no halo needed
+    add(0, m0, 1, 1);
+    add(m1, rows, 1, 1);
+    return n;
 }
 
 // Direct xGMI copies between the tiles' devices: without peer access hipMemcpyPeerAsync stages through
@@ -162,7 +153,7 @@ int32_t for_tiles(int n, const int32_t *live, bool threaded, F f) {
 
 // Halo pull of tile k: up to R rows of the H-blurred planes (planar (3, rows + 2R, W)) from the tiles above and below
 // (a tile thinner than R passes the request on to the next one), queued on `stream` behind the producers' events.
-// pipelined: wait for the neighbour's `halo_ready` when its halo band covers the rows, for `h_all` otherwise.
+// pipelined: behind the neighbour's `halo_ready` (its H pass), serial: behind its ev[3].
 int32_t queue_halo_pull(bhr_ctx **ctxs, int n, int k, hipStream_t stream, bool pipelined) {
     bhr_ctx *me = ctxs[k];
     const size_t R = me->bloom_R, W = me->cfg.width, my_rows = me->rows;
@@ -174,10 +165,7 @@ int32_t queue_halo_pull(bhr_ctx **ctxs, int n, int k, hipStream_t stream, bool p
             const size_t take = (size_t)nb->rows < need ? (size_t)nb->rows : need;
             if (pipelined) {
                 const TilePipe *np = (const TilePipe *)nb->pipe;
-                if (np) {                          // a tile that has never rendered pipelined has nothing in flight
-                    const bool in_band = side == 0 ? (int)take <= nb->rows - np->band_bot : (int)take <= np->band_top;
-                    BHR_HIP(hipStreamWaitEvent(stream, in_band ? np->halo_ready : np->h_all, 0));
-                }
+                if (np) BHR_HIP(hipStreamWaitEvent(stream, np->halo_ready, 0));   // a tile that never rendered pipelined has nothing in flight
             } else {
                 BHR_HIP(hipStreamWaitEvent(stream, nb->ev[3], 0));
             }
@@ -318,78 +306,19 @@ int32_t render_pipelined(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t 
     const bool gather = (flags & (BHR_GATHER_PEER | BHR_GATHER_U8)) != 0;
     bhr_ctx *head = ctxs[0];
     if (gather) BHR_TRY(ensure_gather(head, flags));
-    int n_chunks_want = 3;
-    if (const char *e = getenv("BHR_TILE_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= PIPE_MAX_CHUNKS) n_chunks_want = v; }
 
-    // phase 1: march (halo bands first) and H passes
+    // phase 1: march and H pass on the tile's stream
     BHR_TRY(for_tiles(n, live, threaded, [&](int k) -> int32_t {
         bhr_ctx *c = ctxs[k];
         BHR_TRY(bhr_enter(c));
         c->cur_slot = -1;
         c->last_slot = -1;
-        BHR_TRY(ensure_pipe(c, with_bloom && k > 0, with_bloom && k < n - 1));
+        BHR_TRY(ensure_pipe(c));
         TilePipe *p = (TilePipe *)c->pipe;
-        const bool split = with_bloom && p->n_band > 0 && p->n_rest > 0 && !(flags & (BHR_PERSISTENT | BHR_ROW_COSTS));
-        auto march = [&]() -> int32_t {
-            if (!split) {
-                BHR_TRY(bhr_launch_march(c, cam, flags));
-                BHR_HIP(hipEventRecord(p->march_a, c->stream));
-                BHR_HIP(hipEventRecord(p->march_b, c->stream));
-                return BHR_OK;
-            }
-            // the halo bands on the tile's stream, the rows between them on its low-priority second stream: they start
-            // together, the bands' workgroups are dispatched first, the rest fills the slots the bands leave -- no drain
-            // between the two launches.  Bracket (start event, counter clear / end event) = empty first / last part.
-            bhr_march_part part;
-            memset(&part, 0, sizeof(part));
-            part.active = 1;
-            part.id = 1; part.first = 1;
-            c->part = part;
-            BHR_TRY(bhr_launch_march(c, cam, flags));                              // prologue
-            const bool two = !(getenv("BHR_PIPE_MARCH_STREAMS") && atoi(getenv("BHR_PIPE_MARCH_STREAMS")) == 1);
-            if (two) BHR_TRY(bhr_aux_fork(c));
-            part.d_list = p->d_band; part.h_list = p->h_band; part.n = p->n_band; part.first = 0; part.last = 0;
-            c->part = part;
-            BHR_TRY(bhr_launch_march(c, cam, flags));
-            BHR_HIP(hipEventRecord(p->march_a, c->stream));
-            hipStream_t main_stream = c->stream;
-            if (two) c->stream = c->aux_stream;
-            part.d_list = p->d_band + p->n_band; part.h_list = p->h_band + p->n_band; part.n = p->n_rest; part.id = 2;
-            c->part = part;
-            const int32_t rc_rest = bhr_launch_march(c, cam, flags);
-            c->stream = main_stream;
-            BHR_TRY(rc_rest);
-            if (two) BHR_TRY(bhr_aux_join(c));
-            BHR_HIP(hipEventRecord(p->march_b, c->stream));
-            part.d_list = nullptr; part.h_list = nullptr; part.n = 0; part.last = 1;
-            c->part = part;
-            BHR_TRY(bhr_launch_march(c, cam, flags));                              // epilogue: the end event
-            return BHR_OK;
-        };
-        const int32_t rc_m = march();
-        c->part.active = 0;
-        BHR_TRY(rc_m);
-        // H passes on the post stream: the halo bands as soon as their march is done, the rest behind the second launch
-        auto h_passes = [&]() -> int32_t {
-            BHR_HIP(hipStreamWaitEvent(p->post, p->march_a, 0));
-            if (!split) BHR_HIP(hipStreamWaitEvent(p->post, p->march_b, 0));
-            if (with_bloom && split) {
-                BHR_TRY(bhr_launch_bloom_h_rows(c, 0, p->band_top));
-                BHR_TRY(bhr_launch_bloom_h_rows(c, p->band_bot, c->rows));
-            } else if (with_bloom) {
-                BHR_TRY(bhr_launch_bloom_h(c));
-            }
-            BHR_HIP(hipEventRecord(p->halo_ready, p->post));
-            BHR_HIP(hipStreamWaitEvent(p->post, p->march_b, 0));
-            if (with_bloom && split) BHR_TRY(bhr_launch_bloom_h_rows(c, p->band_top, p->band_bot));
-            BHR_HIP(hipEventRecord(p->h_all, p->post));
-            return BHR_OK;
-        };
-        hipStream_t main_stream = c->stream;
-        c->stream = p->post;
-        const int32_t rc_h = h_passes();
-        c->stream = main_stream;
-        return rc_h;
+        BHR_TRY(bhr_launch_march(c, cam, flags));
+        if (with_bloom) BHR_TRY(bhr_launch_bloom_h(c));
+        BHR_HIP(hipEventRecord(p->halo_ready, c->stream));
+        return BHR_OK;
     }));
 
     // phase 2: halo pulls on the copy streams, behind the neighbours' halo_ready
@@ -402,37 +331,28 @@ int32_t render_pipelined(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t 
             BHR_HIP(hipEventRecord(p->halo_in, p->copy));
         }
 
-    // phase 3: V pass + combine in row chunks on the post stream; every finished chunk is pushed by the copy stream
+    // phase 3: V pass + combine in row chunks -- the rows that need no halo first, under the halo pull -- every finished
+    // chunk pushed by the push stream while the next chunk's V kernel runs
     for (int k = 0; k < n; ++k) {
         if (live && !live[k]) continue;
         bhr_ctx *c = ctxs[k];
         TilePipe *p = (TilePipe *)c->pipe;
         BHR_HIP(hipSetDevice(c->cfg.device));
-        if (with_bloom && n > 1) BHR_HIP(hipStreamWaitEvent(p->post, p->halo_in, 0));
-        const int vb = bhr_bloom_v_tile_rows(c);
-        int chunk = (c->rows + n_chunks_want - 1) / n_chunks_want;
-        chunk = ((chunk + vb - 1) / vb) * vb;
+        const bool halo = with_bloom && n > 1;
+        Chunk chunks[PIPE_MAX_CHUNKS];
+        const int n_chunks = plan_chunks(c, halo && k > 0, halo && k < n - 1, bhr_bloom_v_tile_rows(c), chunks);
         const bool push_chunks = gather && !flare;
-        auto v_passes = [&]() -> int32_t {
-            int ci = 0;
-            for (int r0 = 0; r0 < c->rows; r0 += chunk, ++ci) {
-                const int r1 = r0 + chunk < c->rows ? r0 + chunk : c->rows;
-                BHR_TRY(bhr_launch_bloom_v_rows(c, with_bloom, r0, r1, (push_chunks && (flags & BHR_GATHER_U8)) ? c->d_final_u8 : nullptr));
-                if (!push_chunks) continue;
-                BHR_HIP(hipEventRecord(p->v_done[ci], p->post));
-                BHR_HIP(hipStreamWaitEvent(p->copy, p->v_done[ci], 0));
-                BHR_TRY(queue_push(head, c, flags, r0, r1, p->copy));
-            }
-            return BHR_OK;
-        };
-        hipStream_t main_stream = c->stream;
-        c->stream = p->post;
-        const int32_t rc_v = v_passes();
-        c->stream = main_stream;
-        BHR_TRY(rc_v);
-        BHR_HIP(hipEventRecord(p->post_done, p->post));
-        BHR_HIP(hipEventRecord(p->landed, p->copy));
-        BHR_HIP(hipStreamWaitEvent(c->stream, p->post_done, 0));
+        bool waited = false;
+        for (int ci = 0; ci < n_chunks; ++ci) {
+            if (chunks[ci].needs_halo && !waited) { BHR_HIP(hipStreamWaitEvent(c->stream, p->halo_in, 0)); waited = true; }
+            BHR_TRY(bhr_launch_bloom_v_rows(c, with_bloom, chunks[ci].r0, chunks[ci].r1, (push_chunks && (flags & BHR_GATHER_U8)) ? c->d_final_u8 : nullptr));
+            if (!push_chunks) continue;
+            BHR_HIP(hipEventRecord(p->v_done[ci], c->stream));
+            BHR_HIP(hipStreamWaitEvent(p->push, p->v_done[ci], 0));
+            BHR_TRY(queue_push(head, c, flags, chunks[ci].r0, chunks[ci].r1, p->push));
+        }
+        if (halo && !waited) BHR_HIP(hipStreamWaitEvent(c->stream, p->halo_in, 0));   // nothing of this frame stays in flight
+        BHR_HIP(hipEventRecord(p->landed, p->push));
         BHR_HIP(hipStreamWaitEvent(c->stream, p->landed, 0));
         c->last_flags = (int32_t)flags;
         c->timing_valid = 1;
@@ -462,15 +382,13 @@ void bhr_pipe_free(bhr_ctx *ctx) {
     if (!p) return;
     for (void *o : p->opened)
         if (o) (void)hipIpcCloseMemHandle(o);
-    if (p->post) { (void)hipStreamSynchronize(p->post); (void)hipStreamDestroy(p->post); }
     if (p->copy) { (void)hipStreamSynchronize(p->copy); (void)hipStreamDestroy(p->copy); }
-    hipEvent_t evs[] = {p->march_a, p->march_b, p->halo_ready, p->h_all, p->halo_in, p->landed, p->post_done, p->glow_ready};
+    if (p->push) { (void)hipStreamSynchronize(p->push); (void)hipStreamDestroy(p->push); }
+    hipEvent_t evs[] = {p->halo_ready, p->halo_in, p->landed};
     for (hipEvent_t ev : evs)
         if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : p->v_done)
         if (ev) (void)hipEventDestroy(ev);
-    if (p->d_band) (void)hipFree(p->d_band);
-    free(p->h_band);
     delete p;
     ctx->pipe = nullptr;
 }
@@ -502,7 +420,8 @@ int32_t bhr_group_render_subset(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam
     }
     bool threaded = n_live > 1 && distinct_devices;
     if (const char *e = getenv("BHR_GROUP_THREADS")) threaded = n_live > 1 && atoi(e) != 0;   // test knob: force / forbid
-    bool serial = (flags & BHR_GROUP_SERIAL) != 0;
+    // tiles that share a device copy HBM to HBM: nothing to hide, the serial schedule has fewer hand-overs
+    bool serial = (flags & BHR_GROUP_SERIAL) != 0 || (!(flags & BHR_GROUP_PIPELINED) && !distinct_devices);
     if (const char *e = getenv("BHR_GROUP_SCHEDULE")) serial = e[0] == 's';                   // "serial" | "pipelined": A/B runs
     return serial ? render_serial(ctxs, n, cam, flags, out_host, live, threaded)
                   : render_pipelined(ctxs, n, cam, flags, out_host, live, threaded);
@@ -559,7 +478,7 @@ int32_t bhr_tile_connect(bhr_ctx *ctx, int32_t rank, int32_t world, const bhr_ti
     if (expect != ctx->cfg.height || all[rank].row0 != ctx->cfg.row0 || all[rank].rows != ctx->rows)
         return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: the handles do not describe this frame / this rank's tile");
     const int with_up = rank > 0, with_down = rank < world - 1;
-    BHR_TRY(ensure_pipe(ctx, with_up, with_down));
+    BHR_TRY(ensure_pipe(ctx));
     TilePipe *p = (TilePipe *)ctx->pipe;
     for (void *&o : p->opened) {
         if (o) (void)hipIpcCloseMemHandle(o);
@@ -619,108 +538,52 @@ int32_t bhr_tile_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     BHR_TRY(bhr_enter(ctx));
     ctx->cur_slot = -1;
     ctx->last_slot = -1;
-    const bool split = with_bloom && p->n_band > 0 && p->n_rest > 0 && !(flags & (BHR_PERSISTENT | BHR_ROW_COSTS));
-    // march: halo bands on the tile's stream, the rest on the low-priority second stream (as render_pipelined)
-    auto march = [&]() -> int32_t {
-        if (!split) {
-            BHR_TRY(bhr_launch_march(ctx, cam, flags));
-            BHR_HIP(hipEventRecord(p->march_a, ctx->stream));
-            BHR_HIP(hipEventRecord(p->march_b, ctx->stream));
-            return BHR_OK;
-        }
-        bhr_march_part part;
-        memset(&part, 0, sizeof(part));
-        part.active = 1; part.id = 1; part.first = 1;
-        ctx->part = part;
-        BHR_TRY(bhr_launch_march(ctx, cam, flags));
-        BHR_TRY(bhr_aux_fork(ctx));
-        part.d_list = p->d_band; part.h_list = p->h_band; part.n = p->n_band; part.first = 0;
-        ctx->part = part;
-        BHR_TRY(bhr_launch_march(ctx, cam, flags));
-        BHR_HIP(hipEventRecord(p->march_a, ctx->stream));
-        hipStream_t main_stream = ctx->stream;
-        ctx->stream = ctx->aux_stream;
-        part.d_list = p->d_band + p->n_band; part.h_list = p->h_band + p->n_band; part.n = p->n_rest; part.id = 2;
-        ctx->part = part;
-        const int32_t rc = bhr_launch_march(ctx, cam, flags);
-        ctx->stream = main_stream;
-        BHR_TRY(rc);
-        BHR_TRY(bhr_aux_join(ctx));
-        BHR_HIP(hipEventRecord(p->march_b, ctx->stream));
-        part.d_list = nullptr; part.h_list = nullptr; part.n = 0; part.last = 1;
-        ctx->part = part;
-        BHR_TRY(bhr_launch_march(ctx, cam, flags));
+    // march -> H pass on the tile's stream
+    BHR_TRY(bhr_launch_march(ctx, cam, flags));
+    if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctx));
+    BHR_HIP(hipEventRecord(p->halo_ready, ctx->stream));
+    const bool halo = with_bloom && world > 1;
+    const bool gather = (flags & (BHR_GATHER_PEER | BHR_GATHER_U8)) != 0;
+    Chunk chunks[PIPE_MAX_CHUNKS];
+    const int n_chunks = plan_chunks(ctx, halo && rank > 0, halo && rank < world - 1, bhr_bloom_v_tile_rows(ctx), chunks);
+    // V pass + combine of chunk ci on the tile's stream, its rows pushed into tile 0's frame buffers by the push stream
+    auto v_chunk = [&](int ci) -> int32_t {
+        const int r0 = chunks[ci].r0, r1 = chunks[ci].r1;
+        BHR_TRY(bhr_launch_bloom_v_rows(ctx, with_bloom, r0, r1, (flags & BHR_GATHER_U8) ? ctx->d_final_u8 : nullptr));
+        if (!gather) return BHR_OK;
+        BHR_HIP(hipEventRecord(p->v_done[ci], ctx->stream));
+        BHR_HIP(hipStreamWaitEvent(p->push, p->v_done[ci], 0));
+        const size_t W3 = W * 3, off = (size_t)r0 * W3, cnt = (size_t)(r1 - r0) * W3, dst = (size_t)(ctx->cfg.row0 + r0) * W3;
+        if (flags & BHR_GATHER_U8)
+            BHR_HIP(hipMemcpyAsync(p->gather_u8 + dst, ctx->d_final_u8 + off, cnt, hipMemcpyDeviceToDevice, p->push));
+        if (flags & BHR_GATHER_PEER)
+            BHR_HIP(hipMemcpyAsync(p->gather_f32 + dst, ctx->d_final + off, cnt * sizeof(float), hipMemcpyDeviceToDevice, p->push));
         return BHR_OK;
     };
-    const int32_t rc_m = march();
-    ctx->part.active = 0;
-    BHR_TRY(rc_m);
-    hipStream_t main_stream = ctx->stream;
-    auto on_post = [&](auto f) -> int32_t {
-        ctx->stream = p->post;
-        const int32_t rc = f();
-        ctx->stream = main_stream;
-        return rc;
-    };
-    BHR_TRY(on_post([&]() -> int32_t {
-        BHR_HIP(hipStreamWaitEvent(p->post, p->march_a, 0));
-        if (!split) BHR_HIP(hipStreamWaitEvent(p->post, p->march_b, 0));
-        if (with_bloom && split) {
-            BHR_TRY(bhr_launch_bloom_h_rows(ctx, 0, p->band_top));
-            BHR_TRY(bhr_launch_bloom_h_rows(ctx, p->band_bot, ctx->rows));
-        } else if (with_bloom) {
-            BHR_TRY(bhr_launch_bloom_h(ctx));
-        }
-        BHR_HIP(hipEventRecord(p->halo_ready, p->post));
-        BHR_HIP(hipStreamWaitEvent(p->post, p->march_b, 0));
-        if (with_bloom && split) BHR_TRY(bhr_launch_bloom_h_rows(ctx, p->band_top, p->band_bot));
-        BHR_HIP(hipEventRecord(p->h_all, p->post));
-        return BHR_OK;
-    }));
-    if (with_bloom && world > 1) {
-        // my halo bands are blurred: tell the neighbours; then pull theirs once they have said the same
+    // the rows that need no halo are queued now: they run while this rank waits for its neighbours below
+    for (int ci = 0; ci < n_chunks; ++ci)
+        if (!chunks[ci].needs_halo) BHR_TRY(v_chunk(ci));
+    if (halo) {
+        // my rows are blurred: tell the neighbours; then pull theirs once they have said the same
         BHR_HIP(hipEventSynchronize(p->halo_ready));
         __atomic_store_n(mine + 0, frame, __ATOMIC_RELEASE);
         for (int side = 0; side < 2; ++side) {
             if (!p->nb_hblur[side]) continue;
             const int nb = side == 0 ? rank - 1 : rank + 1;
-            BHR_TRY(wait_counter(p->shm + (size_t)nb * BHR_TILE_SHM_WORDS, frame, "halo bands", nb));
+            BHR_TRY(wait_counter(p->shm + (size_t)nb * BHR_TILE_SHM_WORDS, frame, "halo rows", nb));
             const size_t nb_rows = p->nb_rows[side], nb_plane = (nb_rows + 2 * R) * W, my_plane = (rows + 2 * R) * W;
-            const size_t src_row = side == 0 ? R + nb_rows - R : R;        // its last / first R rows (own rows live at [R, R + rows))
+            const size_t src_row = side == 0 ? nb_rows : R;                  // its last / first R rows (own rows live at [R, R + rows))
             const size_t dst_row = side == 0 ? 0 : R + rows;
             for (int c = 0; c < 3; ++c)
                 BHR_HIP(hipMemcpyAsync(ctx->d_hblur + c * my_plane + dst_row * W, p->nb_hblur[side] + c * nb_plane + src_row * W,
                                        R * W * sizeof(float), hipMemcpyDeviceToDevice, p->copy));
         }
         BHR_HIP(hipEventRecord(p->halo_in, p->copy));
-        BHR_HIP(hipStreamWaitEvent(p->post, p->halo_in, 0));
+        BHR_HIP(hipStreamWaitEvent(ctx->stream, p->halo_in, 0));
     }
-    // V pass + combine in row chunks, every finished chunk pushed into tile 0's frame buffers by the copy stream
-    int n_chunks_want = 3;
-    if (const char *e = getenv("BHR_TILE_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= PIPE_MAX_CHUNKS) n_chunks_want = v; }
-    const int vb = bhr_bloom_v_tile_rows(ctx);
-    int chunk = (ctx->rows + n_chunks_want - 1) / n_chunks_want;
-    chunk = ((chunk + vb - 1) / vb) * vb;
-    const bool gather = (flags & (BHR_GATHER_PEER | BHR_GATHER_U8)) != 0;
-    BHR_TRY(on_post([&]() -> int32_t {
-        int ci = 0;
-        for (int r0 = 0; r0 < ctx->rows; r0 += chunk, ++ci) {
-            const int r1 = r0 + chunk < ctx->rows ? r0 + chunk : ctx->rows;
-            BHR_TRY(bhr_launch_bloom_v_rows(ctx, with_bloom, r0, r1, (flags & BHR_GATHER_U8) ? ctx->d_final_u8 : nullptr));
-            if (!gather) continue;
-            BHR_HIP(hipEventRecord(p->v_done[ci], p->post));
-            BHR_HIP(hipStreamWaitEvent(p->copy, p->v_done[ci], 0));
-            const size_t W3 = W * 3, off = (size_t)r0 * W3, cnt = (size_t)(r1 - r0) * W3, dst = (size_t)(ctx->cfg.row0 + r0) * W3;
-            if (flags & BHR_GATHER_U8)
-                BHR_HIP(hipMemcpyAsync(p->gather_u8 + dst, ctx->d_final_u8 + off, cnt, hipMemcpyDeviceToDevice, p->copy));
-            if (flags & BHR_GATHER_PEER)
-                BHR_HIP(hipMemcpyAsync(p->gather_f32 + dst, ctx->d_final + off, cnt * sizeof(float), hipMemcpyDeviceToDevice, p->copy));
-        }
-        return BHR_OK;
-    }));
-    BHR_HIP(hipEventRecord(p->post_done, p->post));
-    BHR_HIP(hipEventRecord(p->landed, p->copy));
-    BHR_HIP(hipStreamWaitEvent(ctx->stream, p->post_done, 0));
+    for (int ci = 0; ci < n_chunks; ++ci)
+        if (chunks[ci].needs_halo) BHR_TRY(v_chunk(ci));
+    BHR_HIP(hipEventRecord(p->landed, p->push));
     BHR_HIP(hipStreamWaitEvent(ctx->stream, p->landed, 0));
     BHR_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     ctx->last_flags = (int32_t)flags;

@@ -80,19 +80,20 @@ def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
 
 
 def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_differentials=False,
-                 skip_bloom=False, lens_flare=False, gather: str = "host", schedule: str = "pipelined", live=None):
+                 skip_bloom=False, lens_flare=False, gather: str = "host", schedule: str = "auto", live=None):
     """Render one frame with the row-block renderers ``tiles`` (HipRenderer objects whose rows tile
     the image in order).  gather="host": returns the (H, W, 3) float32 frame, assembled from per-device pinned
     buffers.  gather="peer": the tiles are gathered on tiles[0]'s device with hipMemcpyPeerAsync (xGMI) and stay
     there -- returns None, read_gathered(tiles) fetches the frame.  gather="peer_u8": the same with the quantised
     rows (a quarter of the bytes; read_gathered_u8).  gather="none": the rows stay in their tiles.
-    schedule: "pipelined" (default; halo bands first, halo pulls and row-chunk pushes under the march / the V pass,
-    csrc/group.hip) or "serial" (step after step; same bytes).  live: per-tile 0/1 -- only those tiles render, the
+    schedule: "pipelined" (halo pull under the V pass of the rows that need no halo, row chunks pushed while the next
+    chunk's V kernel runs, csrc/group.hip), "serial" (step after step; same bytes) or "auto" (default: pipelined where the
+    tiles sit on distinct devices, serial where they share one).  live: per-tile 0/1 -- only those tiles render, the
     others keep the buffers of the last call in which they did (bench.py times one tile of eight that way)."""
     if gather not in ("host", "peer", "peer_u8", "none"):
         raise ValueError(f"gather must be 'host', 'peer', 'peer_u8' or 'none', got {gather!r}")
-    if schedule not in ("pipelined", "serial"):
-        raise ValueError(f"schedule must be 'pipelined' or 'serial', got {schedule!r}")
+    if schedule not in ("auto", "pipelined", "serial"):
+        raise ValueError(f"schedule must be 'auto', 'pipelined' or 'serial', got {schedule!r}")
     first = tiles[0]
     lib = _lib.load()
     arr = (C.c_void_p * len(tiles))(*[t._ctx for t in tiles])
@@ -100,8 +101,7 @@ def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_diff
     flags = first._flags(skip_differentials, skip_bloom)
     if lens_flare:
         flags |= _lib.LENS_FLARE
-    if schedule == "serial":
-        flags |= _lib.GROUP_SERIAL
+    flags |= {"auto": 0, "serial": _lib.GROUP_SERIAL, "pipelined": _lib.GROUP_PIPELINED}[schedule]
     flags |= {"host": 0, "none": 0, "peer": _lib.GATHER_PEER, "peer_u8": _lib.GATHER_U8}[gather]
     live_arr = None
     if live is not None:

@@ -105,8 +105,11 @@ typedef struct {
 #define BHR_GATHER_U8        512u  /* bhr_group_render: gather the QUANTISED rows ((H, W, 3) u8, save_image's truncation, render.py:423)
                                       on ctxs[0]'s device -- a quarter of the f32 bytes over xGMI; the pipelined schedule
                                       ships every row chunk as soon as its V pass has written it */
-#define BHR_GROUP_SERIAL    1024u  /* bhr_group_render: the serial schedule (march -> H -> halo -> V -> gather per tile) instead
-                                      of the pipelined one; same bytes */
+#define BHR_GROUP_SERIAL    1024u  /* bhr_group_render: the serial schedule (march -> H -> halo -> V -> gather, each behind the other
+                                      on the tile's stream); same bytes as the pipelined one */
+#define BHR_GROUP_PIPELINED 2048u  /* bhr_group_render: the pipelined schedule (halo pull under the V pass of the middle rows, row
+                                      chunks pushed while the next chunk's V kernel runs).  Neither flag: pipelined where the
+                                      tiles sit on distinct devices, serial where they share one */
 #define BHR_GATHER_PEER      128u  /* bhr_group_render: gather the tiles into one (H, W, 3) buffer on ctxs[0]'s device with
                                       hipMemcpyPeerAsync (xGMI), one copy per tile on the tile's own stream */
 
@@ -265,9 +268,9 @@ BHR_API int32_t bhr_get_row_costs(bhr_ctx *ctx, uint64_t *out, int32_t n);
  * hipMemcpyPeerAsync, runs the V pass per tile and gathers the final tiles:
  * with BHR_GATHER_PEER into a full-frame f32 buffer on ctxs[0]'s device, with BHR_GATHER_U8 into a quantised u8 one
  * (peer copies over xGMI, no collective), and, if out_host != NULL, into out_host (H, W, 3) through per-device pinned
- * buffers.  Pipelined by default (csrc/group.hip): every tile marches its halo bands first, pulls its neighbours'
- * halo rows under the march of the remaining rows, and pushes finished row chunks while the next chunk's V pass
- * runs; BHR_GROUP_SERIAL selects the step-after-step schedule.  Same bytes either way.  Synchronises. */
+ * buffers.  Two schedules (csrc/group.hip), same bytes: pipelined -- the halo pull runs under the V pass of the rows
+ * that need no halo, finished row chunks are pushed while the next chunk's V pass runs -- and serial; see
+ * BHR_GROUP_SERIAL / BHR_GROUP_PIPELINED.  Synchronises. */
 BHR_API int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host);
 /* The same with only the tiles k with live[k] != 0 rendering; the others keep the buffers (halo rows, gathered rows,
  * glow rows) of the last call in which they were live.  live == NULL: all.  Times one tile of N end to end on one

@@ -37,6 +37,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bench_ramp.json"))
     ap.add_argument("--math", default=None)
+    ap.add_argument("--spin-up-ms", type=float, default=0.0, help="un-timed frames for this long before the first region (bench.py's spin-up)")
     a = ap.parse_args()
     wl = bench.WORKLOADS["fhd"]
     res = {}
@@ -45,6 +46,11 @@ def main():
         r, _, _, _ = workloads.make_scene(wl, math=a.math, frame_slots=slots)
         setup = time.perf_counter() - t0
         runs = []
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < a.spin_up_ms:
+            for _ in range(8):
+                r.render_async(wl["cam_pos"], wl["fov"])
+            r.sync()
         # the driver's counts FIRST, straight after the scene set-up (as in a fresh bench.py process), then again, then long
         for warm, steps in ((5, 20), (5, 20), (20, 200), (5, 20)):
             runs.append(region(r, wl, warm, steps))

@@ -7,10 +7,10 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from bhr_amd import HipRenderer, _lib, scenes
 
-SIZES = {"8k": (7680, 4320, None, 0.05), "8ktile": (7680, 4320, (1088, 1616), 0.05), "4k": (3840, 2160, None, 0.1),
+SIZES = {"8k": (7680, 4320, None, 0.05), "4k": (3840, 2160, None, 0.1),
          "fhd": (1920, 1080, None, 0.1)}
-H_VARIANTS = ["0", "1", "2", "4"]
-V_VARIANTS = ["32x0", "32x1", "32x2", "32x4", "32x8", "16x1", "16x2", "16x4", "16x8"]
+H_VARIANTS = ["0", "2l", "mfma1", "mfma2", "mfma4"]          # "<NG>l": weights in LDS (VGPR operands)
+V_VARIANTS = ["32x0", "16x2", "16x4", "16x4l", "mfma1", "mfma2", "mfma4"]
 
 
 def time_pass(r, only, n):
@@ -29,7 +29,7 @@ def time_pass(r, only, n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sizes", default="8k,8ktile,4k,fhd")
+    ap.add_argument("--sizes", default="8k,4k,fhd")
     ap.add_argument("--quick", default=None, help="H,V variant pair only (profiling), e.g. 0,32x0")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bloom_variants.json"))
     a = ap.parse_args()
@@ -37,14 +37,15 @@ def main():
     for name in a.sizes.split(","):
         W, H, rows, step = SIZES[name]
         sky, tex = scenes.analytic_skybox(128, 256), scenes.noisy_disk(256, 1024)
-        for k in ("BHR_BLOOM_H", "BHR_BLOOM_V", "BHR_BLOOM_ONLY"):
+        for k in ("BHR_BLOOM_H", "BHR_BLOOM_V", "BHR_BLOOM_ONLY", "BHR_BLOOM_W"):
             os.environ.pop(k, None)
         r = HipRenderer(W, H, sky, tex, step_size=step, rows=rows, frame_slots=1)
         r.render_async([6, 0, 0.5], 90, skip_bloom=True)          # bg + disk layers; halo rows of a row block stay zero
         n = 20 if W > 4000 else 50
         if a.quick:
             hv, vv = a.quick.split(",")
-            os.environ["BHR_BLOOM_H"], os.environ["BHR_BLOOM_V"] = hv, vv
+            os.environ["BHR_BLOOM_W"] = "lds" if (hv.endswith("l") and not hv.startswith("m")) or (vv.endswith("l") and not vv.startswith("m")) else "sgpr"
+            os.environ["BHR_BLOOM_H"], os.environ["BHR_BLOOM_V"] = (hv if hv.startswith("m") else hv.rstrip("l")), (vv if vv.startswith("m") else vv.rstrip("l"))
             print(name, a.quick, "H", round(time_pass(r, "h", n), 4), "V", round(time_pass(r, "v", n), 4), flush=True)
             r.close()
             continue
@@ -52,19 +53,24 @@ def main():
         base_blur, base_final = r.read_layer(_lib.LAYER_BLUR), r.read_layer(_lib.LAYER_FINAL)
         out = {"H": {}, "V": {}}
         for hv in H_VARIANTS:
-            os.environ["BHR_BLOOM_H"] = hv
+            os.environ["BHR_BLOOM_H"] = hv if hv.startswith("m") else hv.rstrip("l")
+            os.environ["BHR_BLOOM_W"] = "lds" if (hv.endswith("l") and not hv.startswith("m")) else "sgpr"
             os.environ["BHR_BLOOM_V"] = "32x0"
             r.bloom_only()
-            same = bool(np.array_equal(r.read_layer(_lib.LAYER_BLUR), base_blur))
-            out["H"][hv] = {"ms": time_pass(r, "h", n), "bit_identical": same}
+            blur = r.read_layer(_lib.LAYER_BLUR)
+            same = bool(np.array_equal(blur, base_blur))
+            out["H"][hv] = {"ms": time_pass(r, "h", n), "bit_identical": same, "max_diff_blur": float(np.abs(blur - base_blur).max())}
             print(name, "H", hv, out["H"][hv], flush=True)
         os.environ["BHR_BLOOM_H"] = "0"
         for vv in V_VARIANTS:
-            os.environ["BHR_BLOOM_V"] = vv
+            os.environ["BHR_BLOOM_V"] = vv if vv.startswith("m") else vv.rstrip("l")
+            os.environ["BHR_BLOOM_W"] = "lds" if (vv.endswith("l") and not vv.startswith("m")) else "sgpr"
             try:
                 r.bloom_only()
-                same = bool(np.array_equal(r.read_layer(_lib.LAYER_BLUR), base_blur) and np.array_equal(r.read_layer(_lib.LAYER_FINAL), base_final))
-                out["V"][vv] = {"ms": time_pass(r, "v", n), "bit_identical": same}
+                blur, fin = r.read_layer(_lib.LAYER_BLUR), r.read_layer(_lib.LAYER_FINAL)
+                same = bool(np.array_equal(blur, base_blur) and np.array_equal(fin, base_final))
+                out["V"][vv] = {"ms": time_pass(r, "v", n), "bit_identical": same, "max_diff_blur": float(np.abs(blur - base_blur).max()),
+                                "max_diff_final": float(np.abs(fin - base_final).max()), "blur_max": float(base_blur.max())}
             except Exception as e:
                 out["V"][vv] = {"error": str(e)[:200]}
             print(name, "V", vv, out["V"][vv], flush=True)

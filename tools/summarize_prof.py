@@ -62,7 +62,7 @@ for sub in ("pmc_a", "pmc_b", "pmc_fetch", "pmc_write"):
 
 if traffic_args:
     import json
-    workload, path = traffic_args
+    workload, path = traffic_args                    # workload key, e.g. "fhd/hybrid" (bench.py looks up "<workload>/<math>")
     vals = {}
     for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         f = find(sub, "counter_collection.csv")
@@ -72,17 +72,18 @@ if traffic_args:
                 k = short(r["Kernel_Name"])
                 tot[k] += float(r["Counter_Value"])
                 n[k] += 1
-        k = max(n, key=lambda q: tot[q])             # the dominant march instantiation of this workload
-        vals[name] = (k, tot[k] / n[k], n[k])
+        frames = max(n.values())                     # a hybrid march is two kernels per frame: their bytes add up
+        vals[name] = ({k: round(tot[k] / n[k], 1) for k in n}, sum(tot.values()) / frames, frames)
     tj = json.load(open(path)) if os.path.isfile(path) else {}
     tj[workload] = (vals["FETCH_SIZE"][1] + vals["WRITE_SIZE"][1]) * 1024.0
-    tj[f"_{workload}_detail"] = {"kernel": vals["FETCH_SIZE"][0], "FETCH_SIZE_KiB": vals["FETCH_SIZE"][1],
-                                 "WRITE_SIZE_KiB": vals["WRITE_SIZE"][1], "launches": vals["FETCH_SIZE"][2],
+    tj[f"_{workload}_detail"] = {"kernels_FETCH_SIZE_KiB_per_launch": vals["FETCH_SIZE"][0], "kernels_WRITE_SIZE_KiB_per_launch": vals["WRITE_SIZE"][0],
+                                 "FETCH_SIZE_KiB_per_frame": vals["FETCH_SIZE"][1], "WRITE_SIZE_KiB_per_frame": vals["WRITE_SIZE"][1],
+                                 "frames": vals["FETCH_SIZE"][2],
                                  "profile": f"profiles/{os.path.basename(out).replace('prof_', '')}.md",
                                  "commit": os.environ.get("BHR_COMMIT", "unknown")}
-    tj["source"] = "tools/summarize_prof.py from the pmc_fetch / pmc_write CSVs of tools/profile.sh; per workload: _<workload>_detail"
-    tj["_note"] = ("HBM bytes per march launch from rocprofv3 --pmc (separate passes): (FETCH_SIZE + WRITE_SIZE) KiB x 1024. "
+    tj["source"] = "tools/summarize_prof.py from the pmc_fetch / pmc_write CSVs of tools/profile.sh; per workload/math: _<key>_detail"
+    tj["_note"] = ("HBM bytes per march (all its launches of one frame) from rocprofv3 --pmc (separate passes): (FETCH_SIZE + WRITE_SIZE) KiB x 1024. "
                    "WRITE_SIZE equals the two f32 framebuffers; FETCH_SIZE is uncalibrated for this kernel's 12-16 B gathers "
                    "(MI355X_MICROARCH.md: the x2 correction applies to wide coalesced streams only) and is reported uncorrected.")
     json.dump(tj, open(path, "w"), indent=1)
-    print(f"updated {path}: {workload} = {tj[workload]:.0f} B per launch", file=sys.stderr)
+    print(f"updated {path}: {workload} = {tj[workload]:.0f} B per frame", file=sys.stderr)
