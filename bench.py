@@ -359,6 +359,11 @@ def main():
     # frames sharded round-robin over ranks (configs[4]); the camera is the static default pov
     compaction = args.persistent
     flare = bool(wl.get("lens_flare", False))       # configs[2]: on the device, inside the timed step
+    # torch initialises its HIP context at the first torch.cuda call (hundreds of ms with the GPU idle): have that behind
+    # us before the spin-up, not inside the barrier in front of the timed region (it cost the 20-step run of round 2 and
+    # the first hybrid runs of this round 10-13 %: the timed frames started on a chip that had just idled)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
     # Spin-up (un-timed, before the warm-up steps): after the scene set-up -- hundreds of ms of host work with an idle GPU
     # -- the shader clock is low and needs ~20 ms of load to come back; 5 warm-up frames are 4 ms.  Measured on this
     # scene (tools/exp_bench_ramp.py, profiles/r03_bench_ramp.md): the march takes 0.77 ms in the first timed frame of a
@@ -415,6 +420,11 @@ def main():
     if renderer.frame_slots != 1 and rank == 0:
         solo, _, _, _ = workloads.make_scene(wl, device_index=local_rank, math=args.math, frame_slots=1)
         n_iso = max(min(args.steps, 100), 10)
+        t_spin = time.perf_counter()                   # the second scene set-up idled the chip again: spin up as above
+        while (time.perf_counter() - t_spin) * 1e3 < args.spin_up_ms:
+            for _ in range(8):
+                solo.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
+            solo.sync()
         for _ in range(10):
             solo.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
         solo.timing_reset()

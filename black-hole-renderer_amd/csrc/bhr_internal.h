@@ -29,6 +29,7 @@
 #define BHR_STEP_STRIDE 32          // in u64 words
 #define BHR_STEP_CELL (BHR_STEP_LANES * BHR_STEP_STRIDE)
 
+#define BHR_LOD_GUARD 2e-3f         // hybrid anti-aliased march: |lod - boundary| below which a lane is re-marched strict
 #define BHR_FLUSH_COST 5u            // cost of one wave-wide shading pass in wave-steps (row-cost profile)
 #define BHR_VOLUME_OPAQUE 0.9999f   // finite-thickness disk: accumulated opacity at which a ray stops sampling
 
@@ -85,6 +86,7 @@ struct bhr_march_part {
     int32_t id;              // which base list: 0 whole block, 1 halo bands, 2 the rows between them
     int32_t active, first, last;
     int32_t math_resolved;   // the arithmetic has been chosen by the caller (the two launches of a hybrid march)
+    int32_t aa_repair;       // strict-ILP launcher: the fast-marching anti-aliased kernel that re-marches LOD-boundary lanes strict
 };
 
 // Frame slot: the buffers one frame in flight owns.  bhr_render alternates between two slots, each with its own

@@ -325,6 +325,7 @@ __device__ __forceinline__ float4 disk_v2_rgba(const BhrMarchArgs &a, float hit_
 struct Shade {
     V3 accum;
     float alpha_total;
+    int unsure;   // DIFF: some crossing's LOD sat within BHR_LOD_GUARD of a truncation boundary (read by the hybrid AA kernel only)
 };
 // A disk crossing waiting to be shaded.  Crossings of the lanes of a wave are spread over several
 // RK4 steps (measured: ~6 wave-steps per tile see a hit, each with a handful of live lanes), and
@@ -397,6 +398,12 @@ __device__ __forceinline__ void shade_hit(const BhrMarchArgs &a, Shade &sh, floa
         float dudy = dphi_dy * w_f / (2.0f * BHR_PI_F), dvdy = dr_dy * h_f / span;
         float grad_sq = fmaxf(dudx * dudx + dvdx * dvdx, dudy * dudy + dvdy * dvdy);
         float lod = logf(fmaxf(grad_sq, 1.0f)) / logf(2.0f) * a.aa_strength;
+        {
+            // the level is int(clamp(lod, 0, 3)): it jumps at lod = 1, 2, 3.  A crossing whose lod lies within the guard
+            // band of a jump may pick another level under a different rounding of the differentials
+            const float fr = lod - floorf(lod);
+            if (lod > 0.5f && lod < 3.5f && (fr < BHR_LOD_GUARD || fr > 1.0f - BHR_LOD_GUARD)) sh.unsure = 1;
+        }
         lod = fminf(fmaxf(lod, 0.0f), 3.0f);
         lod_i = (int)fminf(fmaxf(lod, 0.0f), (float)(BHR_NUM_MIP_LEVELS - 1));
     }
@@ -529,6 +536,7 @@ struct Ray {
         affine = 0.0f;
         sh.accum = mk(0, 0, 0);
         sh.alpha_total = 0.0f;
+        sh.unsure = 0;
         n_pend = 0;
         step_count = 0;
         done = a.max_iter <= 0 ? 3 : 0;
@@ -669,7 +677,15 @@ struct Ray {
     __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int at) { write_pixel(a, at, done == 2, d, sh); }
 };
 
+#endif  // BHR_MARCH_STRICT
+#if !BHR_MARCH_STRICT || BHR_MARCH_ILP
+// (the ILP-scheduled strict object compiles this struct too, as RayFast: its hybrid anti-aliased kernel marches fast and
+// falls back on the strict Ray for the lanes whose mip level sits on a truncation boundary -- march_tile_aa_hybrid)
+#if BHR_MARCH_STRICT
+#define BHR_FAST_RAY RayFast
 #else
+#define BHR_FAST_RAY Ray
+#endif
 // =============================================================================
 // fast build.  The force is central, so a ray never leaves the plane spanned by the camera
 // position and its initial direction, and RK4 commutes with rotations: marching the 2-D state
@@ -684,7 +700,7 @@ struct Ray {
 // sees only the isotropic term:  J d = c (d - 5 s (s.d)/r^2).
 // =============================================================================
 template <bool DIFF, int SRC = 0>
-struct Ray {
+struct BHR_FAST_RAY {
     float u, w, du, dw;   // position / direction along (g1, g2)
     float m15L2;          // -1.5 * L2
     float ir;             // 1/|p|
@@ -741,6 +757,7 @@ struct Ray {
         affine = 0.0f;
         sh.accum = mk(0, 0, 0);
         sh.alpha_total = 0.0f;
+        sh.unsure = 0;
         n_pend = 0;
         step_count = 0;
         done = a.max_iter <= 0 ? 3 : 0;
@@ -888,7 +905,7 @@ struct Ray {
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, to3d(du, dw), sh); }
     __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int at) { write_pixel(a, at, done == 2, to3d(du, dw), sh); }
 };
-#endif  // BHR_MARCH_STRICT
+#endif  // fast Ray
 
 __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
     unsigned long long s = v;

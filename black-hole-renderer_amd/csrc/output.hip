@@ -6,6 +6,8 @@
 #include "bhr_internal.h"
 #include "../../include/bhr_output.h"
 
+#include <pthread.h>
+#include <signal.h>
 #include <zlib.h>
 
 #include <condition_variable>
@@ -312,8 +314,9 @@ struct bhr_y4m {
     int w = 0, h = 0;
     size_t frame_bytes = 0;
     FILE *f = nullptr;
-    uint8_t *d_yuv = nullptr;
-    struct Slot { uint8_t *host = nullptr; hipEvent_t ev = nullptr; };
+    // every ring slot owns its device planes: the conversion rides the stream of the frame slot that rendered the frame
+    // (bhr_enter_frame), so two frames in flight convert side by side and the scene stream stays free
+    struct Slot { uint8_t *host = nullptr; uint8_t *dev = nullptr; hipEvent_t ev = nullptr; };
     std::vector<Slot> slots;
     std::deque<int> free_slots, jobs;      // jobs in submission order: ONE writer keeps the frame order
     int in_flight = 0;
@@ -327,6 +330,12 @@ struct bhr_y4m {
 
     void work() {
         (void)hipSetDevice(ctx->cfg.device);
+        // a reader that goes away (an encoder exiting on a FIFO / pipe) must surface as a short write, not kill a C
+        // embedder with SIGPIPE: the signal is blocked in this thread, write() then fails with EPIPE
+        sigset_t block;
+        sigemptyset(&block);
+        sigaddset(&block, SIGPIPE);
+        (void)pthread_sigmask(SIG_BLOCK, &block, nullptr);
         for (;;) {
             int slot;
             {
@@ -372,10 +381,11 @@ int32_t bhr_y4m_open(bhr_ctx *ctx, const char *path, int32_t fps_num, int32_t fp
     if (!s->f) { delete s; return bhr_fail(BHR_ERR_INVALID, "bhr_y4m_open: cannot open %s for writing", path); }
     setvbuf(s->f, nullptr, _IOFBF, 1 << 22);
     fprintf(s->f, "YUV4MPEG2 W%d H%d F%d:%d Ip A1:1 C420jpeg XCOLORRANGE=LIMITED\n", s->w, s->h, fps_num, fps_den);
-    hipError_t e = hipMalloc((void **)&s->d_yuv, s->frame_bytes);
+    hipError_t e = hipSuccess;
     s->slots.resize(n_slots);
     for (int k = 0; k < n_slots && e == hipSuccess; ++k) {
         e = hipHostMalloc((void **)&s->slots[k].host, s->frame_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->slots[k].dev, s->frame_bytes);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->slots[k].ev, hipEventDisableTiming);
         s->free_slots.push_back(k);
     }
@@ -400,14 +410,16 @@ int32_t bhr_y4m_submit(bhr_y4m *s) {
         s->in_flight += 1;
     }
     bhr_ctx *ctx = s->ctx;
-    int32_t rc = bhr_enter(ctx);             // the scene stream follows the frame in flight
+    int32_t rc = bhr_enter_frame(ctx);       // the stream that rendered the last frame (behind its post-passes)
     hipError_t e = hipSuccess;
     if (rc == BHR_OK) {
         dim3 block(32, 8), grid(((s->w >> 1) + 31) / 32, ((s->h >> 1) + 7) / 8);
-        hipLaunchKernelGGL(rgb_to_yuv420_kernel, grid, block, 0, ctx->stream, ctx->d_final, s->d_yuv, s->w, s->h);
+        hipLaunchKernelGGL(rgb_to_yuv420_kernel, grid, block, 0, ctx->stream, ctx->d_final, s->slots[slot].dev, s->w, s->h);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(s->slots[slot].host, s->d_yuv, s->frame_bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s->slots[slot].host, s->slots[slot].dev, s->frame_bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(s->slots[slot].ev, ctx->stream);
+        const int32_t rc_leave = bhr_leave_frame(ctx);
+        if (rc == BHR_OK) rc = rc_leave;
     }
     if (e != hipSuccess || rc != BHR_OK) {
         std::lock_guard<std::mutex> lk(s->mu);
@@ -450,12 +462,13 @@ void bhr_y4m_close(bhr_y4m *s) {
     if (s->writer.joinable()) s->writer.join();
     if (s->f) fclose(s->f);
     (void)hipSetDevice(s->ctx->cfg.device);
-    (void)hipStreamSynchronize(s->ctx->scene_stream);   // d_yuv may still be the source of the last copy
+    (void)bhr_enter(s->ctx);                             // joins the frame slots' streams: a slot's planes may still be a copy's source
+    (void)hipStreamSynchronize(s->ctx->scene_stream);
     for (auto &sl : s->slots) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
         if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
     }
-    if (s->d_yuv) (void)hipFree(s->d_yuv);
     delete s;
 }
 
@@ -544,10 +557,15 @@ int32_t bhr_sink_submit(bhr_sink *s, const char *path) {
         if (rc == BHR_OK) rc = rc_leave;
     }
     if (e != hipSuccess || rc != BHR_OK) {
+        // device work queued before the failing step may still write this slot's buffers: the slot goes back to the free
+        // list only once the frame slots' streams have drained (advisor finding, round 2)
+        std::string msg = e != hipSuccess ? std::string("bhr_sink_submit: ") + hipGetErrorString(e) : std::string(bhr_last_error());
+        (void)bhr_enter(ctx);
+        (void)hipStreamSynchronize(ctx->scene_stream);
         std::lock_guard<std::mutex> lk(s->mu);
         s->free_slots.push_back(slot);
         s->in_flight -= 1;
-        return e != hipSuccess ? bhr_fail(BHR_ERR_HIP, "bhr_sink_submit: %s", hipGetErrorString(e)) : rc;
+        return bhr_fail(e != hipSuccess ? BHR_ERR_HIP : rc, "%s", msg.c_str());
     }
     {
         std::lock_guard<std::mutex> lk(s->mu);

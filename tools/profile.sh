@@ -12,7 +12,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # --frame-slots 1: one frame at a time on one stream, so that a kernel's duration is its own (bench.py's default
 # keeps two frames in flight; its kernel_ms / roofline come from such isolated launches as well)
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-math --tile-workload none --frame-slots 1 $@"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --spin-up-ms 0 --no-cpu-baseline --no-other-math --tile-workload none --frame-slots 1 $@"
 # the duration pass runs bench.py's DEFAULT step counts (what the driver runs): 23 launches are not enough for the
 # clocks to settle and read 4 % high; the counter passes only need a few launches
 TRACE="python3 $ROOT/bench.py --no-cpu-baseline --no-other-math --tile-workload none --frame-slots 1 $@"
