@@ -29,7 +29,11 @@
 #define BHR_STEP_STRIDE 32          // in u64 words
 #define BHR_STEP_CELL (BHR_STEP_LANES * BHR_STEP_STRIDE)
 
-#define BHR_LOD_GUARD 2e-3f         // hybrid anti-aliased march: |lod - boundary| below which a lane is re-marched strict
+// hybrid march: guard bands around the algorithm's switches; a lane inside one is re-marched strict (march.hip: march_tile_hybrid)
+#define BHR_LOD_GUARD 2e-3f         // |lod - level boundary| (the fast differentials are good to ~1e-5 in lod away from the ring)
+#define BHR_R2_GUARD 4e-5f          // |r^2 - r_term^2| / r_term^2 of a plane-crossing step (fast positions are good to ~1e-6 relative)
+#define BHR_EDGE_GUARD 2e-5f        // |hit_r - r_edge| / r_edge at the disk's edges
+#define BHR_F_GUARD 2e-6f           // |plane function at new_pos| / |new_pos|: a step that ends on the disk plane
 #define BHR_FLUSH_COST 5u            // cost of one wave-wide shading pass in wave-steps (row-cost profile)
 #define BHR_VOLUME_OPAQUE 0.9999f   // finite-thickness disk: accumulated opacity at which a ray stops sampling
 
@@ -74,6 +78,9 @@ struct BhrMarchArgs {
     int32_t n_tiles;         // 8x8 pixel tiles in the row block
     int32_t tiles_x;
     int32_t n_list;          // launch slots of this launch (= n_tiles, or the length of a hybrid / row-band sub-list)
+    unsigned int *fix_count; // hybrid march: pixels the guard kernel handed over to the strict fix kernel
+    int32_t *fix_list;
+    int32_t fix_cap;
 };
 
 // A partial march launch: the tiles of `d_list` only.  Set by the callers that split one march into several launches --
@@ -86,7 +93,7 @@ struct bhr_march_part {
     int32_t id;              // which base list: 0 whole block, 1 halo bands, 2 the rows between them
     int32_t active, first, last;
     int32_t math_resolved;   // the arithmetic has been chosen by the caller (the two launches of a hybrid march)
-    int32_t aa_repair;       // strict-ILP launcher: the fast-marching anti-aliased kernel that re-marches LOD-boundary lanes strict
+    int32_t repair;          // 1: the fast object's guard kernel (marks lanes on a discontinuity, appends them to the fix list); 2: the strict fix kernel over that list
 };
 
 // Frame slot: the buffers one frame in flight owns.  bhr_render alternates between two slots, each with its own
@@ -184,6 +191,9 @@ struct bhr_ctx {
     hipStream_t aux_stream;
     hipEvent_t aux_fork[BHR_MAX_FRAME_SLOTS], aux_done[BHR_MAX_FRAME_SLOTS];
     void *hybrid;              // hybrid.hip: tile classification cache
+    unsigned int *fix_count;   // fix list of the hybrid march being launched (owned by hybrid.hip, per frame slot)
+    int32_t *fix_list;
+    int32_t fix_cap;
     void *pipe;                // group.hip: streams, events and band lists of the pipelined row-block path
     uint8_t *d_gather_u8;      // (H, W, 3) u8: quantised frame gathered from the tiles (BHR_GATHER_U8), on tile 0
     // lens flare (flare.hip)

@@ -29,6 +29,12 @@ constexpr double B_CRIT = 2.598076211353316;   // 3 sqrt(3) / 2 r_s, r_s = 1
 
 constexpr int HYBRID_LISTS = 3;   // base lists a march can be launched over: whole block, halo bands, the rest (bhr_march_part.id)
 
+struct FixList {           // per frame slot: pixels the fast list's guard kernel leaves to the strict fix kernel
+    unsigned int *d_count;
+    int32_t *d_list;
+    int32_t cap;
+};
+
 struct SlotLists {
     int32_t *d_list;       // the base list partitioned: strict tiles first (launch order kept), then the fast ones
     int32_t *h_pinned;
@@ -39,6 +45,7 @@ struct SlotLists {
 
 struct Hybrid {
     SlotLists slot[BHR_MAX_FRAME_SLOTS][HYBRID_LISTS];
+    FixList fix[BHR_MAX_FRAME_SLOTS];
     // last classification on the host
     std::vector<uint8_t> strict;   // per tile of the row block: marched strict
     double key[8];
@@ -126,6 +133,10 @@ void bhr_hybrid_free(bhr_ctx *ctx) {
             if (s.h_pinned) (void)hipHostFree(s.h_pinned);
             if (s.copied) (void)hipEventDestroy(s.copied);
         }
+    for (auto &f : h->fix) {
+        if (f.d_count) (void)hipFree(f.d_count);
+        if (f.d_list) (void)hipFree(f.d_list);
+    }
     delete h;
     ctx->hybrid = nullptr;
 }
@@ -147,6 +158,7 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     if (!h) {
         h = new Hybrid();
         memset(h->slot, 0, sizeof(h->slot));
+        memset(h->fix, 0, sizeof(h->fix));
         h->valid = 0;
         h->n_strict = 0;
         // band around b_c, in r_s: measured on the fixtures and the fhd / 4k / e2e frames (tools/hybrid_sweep.py)
@@ -203,6 +215,7 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     p.id = id;
     p.active = 1;
     p.math_resolved = 1;
+    p.repair = 0;
     // Two launches.  On ONE stream the fast list waits for the last strict wave (the chip drains in between); on TWO the
     // fast tiles run on the context's low-priority second stream beside the strict ones and fill the slots they leave.
     // The bracket (start event, counter clear / end event) is an empty first / last part on the frame's own stream.
@@ -210,28 +223,61 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     if (const char *e = getenv("BHR_HYBRID_STREAMS")) streams = atoi(e) == 1 ? 1 : 2;
     if (base.active) streams = 1;                    // a pipelined row block already runs its two halves on two streams
     int32_t rc = BHR_OK;
-    auto launch = [&](const int32_t *list, int n, int first, int last, bool strict) -> int32_t {
+    // The fast list's kernel carries guards: a lane that comes within a guard band of one of the algorithm's switches -- the
+    // truncated mip level, a disk crossing in or next to the terminating step, a step that ends on the disk plane, the
+    // disk's edges -- appends its pixel to a fix list instead of writing it, and a third launch marches the listed pixels
+    // with the strict arithmetic (march.hip: march_tile_guard_kernel / march_fix_kernel).  ~0.1 % of the pixels.
+    // Default: on for anti-aliased views -- the mip-level switch alone flips ~300 pixels of a 4k frame (5e-4 RMSE) -- and off
+    // without anti-aliasing, where only the rare switches remain (a step ending exactly on the disk plane: ~1e-6 of the
+    // crossings, pixels any two builds of the reference disagree on as well) and the third, dependent launch costs 17 % of
+    // the fhd frame rate (guard kernel +25 us, fix kernel 55 us: one strict wave's lifetime that nothing overlaps).
+    // BHR_HYBRID_REPAIR=1 / 0 forces it on / off.
+    const bool aa = ctx->cfg.anti_alias != 0 && !(flags & BHR_SKIP_DIFFERENTIALS);
+    bool repair = aa;
+    if (const char *e = getenv("BHR_HYBRID_REPAIR")) repair = atoi(e) != 0;
+    const int slot_k = ctx->active_slot >= 0 && ctx->active_slot < BHR_MAX_FRAME_SLOTS ? ctx->active_slot : 0;
+    FixList &fx = h->fix[slot_k];
+    if (repair && !fx.d_list) {
+        const long long px = (long long)ctx->cfg.width * ctx->rows;
+        fx.cap = (int32_t)(px / 16 < 4096 ? 4096 : (px / 16 > (1 << 22) ? (1 << 22) : px / 16));
+        fx.cap = (fx.cap + 255) / 256 * 256;
+        BHR_HIP(hipMalloc((void **)&fx.d_count, 64));
+        BHR_HIP(hipMalloc((void **)&fx.d_list, (size_t)fx.cap * sizeof(int32_t)));
+    }
+    ctx->fix_count = repair ? fx.d_count : nullptr;
+    ctx->fix_list = repair ? fx.d_list : nullptr;
+    ctx->fix_cap = repair ? fx.cap : 0;
+    auto launch = [&](const int32_t *list, int n, int first, int last, int kind) -> int32_t {   // kind 0 strict list, 1 fast list, 2 fix list
         p.d_list = list; p.n = n; p.first = first; p.last = last;
+        p.repair = kind == 0 ? 0 : (repair ? kind : 0);
         ctx->part = p;
-        return strict ? bhr_launch_march_strict(ctx, cam, f) : bhr_launch_march(ctx, cam, f);
+        return (kind == 0 || kind == 2) ? bhr_launch_march_strict(ctx, cam, f) : bhr_launch_march(ctx, cam, f);
     };
+    const int first0 = base.active ? base.first : 1, last0 = base.active ? base.last : 1;
     if (streams == 1) {
         // longest rays first: the strict tiles are the ones around the photon ring
-        rc = launch(s.d_list, s.n_strict, base.active ? base.first : 1, 0, true);
-        if (rc == BHR_OK) rc = launch(s.d_list + s.n_strict, base_n - s.n_strict, 0, base.active ? base.last : 1, false);
+        rc = launch(s.d_list, s.n_strict, first0, 0, 0);
+        if (rc == BHR_OK && repair) rc = hipMemsetAsync(fx.d_count, 0, sizeof(unsigned int), ctx->stream) == hipSuccess ? BHR_OK : bhr_fail(BHR_ERR_HIP, "hipMemsetAsync failed");
+        if (rc == BHR_OK) rc = launch(s.d_list + s.n_strict, base_n - s.n_strict, 0, repair ? 0 : last0, 1);
+        if (rc == BHR_OK && repair) rc = launch(nullptr, 0, 0, last0, 2);
     } else {
         hipStream_t main_stream = ctx->stream;
-        rc = launch(nullptr, 0, 1, 0, true);                                       // prologue on the frame's stream
+        rc = launch(nullptr, 0, 1, 0, 0);                                          // prologue on the frame's stream
         if (rc == BHR_OK) rc = bhr_aux_fork(ctx);
-        if (rc == BHR_OK) rc = launch(s.d_list, s.n_strict, 0, 0, true);
+        if (rc == BHR_OK) rc = launch(s.d_list, s.n_strict, 0, 0, 0);
         if (rc == BHR_OK) {
             ctx->stream = ctx->aux_stream;
-            rc = launch(s.d_list + s.n_strict, base_n - s.n_strict, 0, 0, false);
+            if (repair && hipMemsetAsync(fx.d_count, 0, sizeof(unsigned int), ctx->stream) != hipSuccess) rc = bhr_fail(BHR_ERR_HIP, "hipMemsetAsync failed");
+            if (rc == BHR_OK) rc = launch(s.d_list + s.n_strict, base_n - s.n_strict, 0, 0, 1);
+            if (rc == BHR_OK && repair) rc = launch(nullptr, 0, 0, 0, 2);
             ctx->stream = main_stream;
         }
         if (rc == BHR_OK) rc = bhr_aux_join(ctx);
-        if (rc == BHR_OK) rc = launch(nullptr, 0, 0, 1, true);                     // epilogue: the end event
+        if (rc == BHR_OK) rc = launch(nullptr, 0, 0, 1, 0);                        // epilogue: the end event
     }
     ctx->part = base;
+    ctx->fix_count = nullptr;
+    ctx->fix_list = nullptr;
+    ctx->fix_cap = 0;
     return rc;
 }

@@ -677,15 +677,7 @@ struct Ray {
     __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int at) { write_pixel(a, at, done == 2, d, sh); }
 };
 
-#endif  // BHR_MARCH_STRICT
-#if !BHR_MARCH_STRICT || BHR_MARCH_ILP
-// (the ILP-scheduled strict object compiles this struct too, as RayFast: its hybrid anti-aliased kernel marches fast and
-// falls back on the strict Ray for the lanes whose mip level sits on a truncation boundary -- march_tile_aa_hybrid)
-#if BHR_MARCH_STRICT
-#define BHR_FAST_RAY RayFast
 #else
-#define BHR_FAST_RAY Ray
-#endif
 // =============================================================================
 // fast build.  The force is central, so a ray never leaves the plane spanned by the camera
 // position and its initial direction, and RK4 commutes with rotations: marching the 2-D state
@@ -700,7 +692,7 @@ struct Ray {
 // sees only the isotropic term:  J d = c (d - 5 s (s.d)/r^2).
 // =============================================================================
 template <bool DIFF, int SRC = 0>
-struct BHR_FAST_RAY {
+struct Ray {
     float u, w, du, dw;   // position / direction along (g1, g2)
     float m15L2;          // -1.5 * L2
     float ir;             // 1/|p|
@@ -840,6 +832,15 @@ struct BHR_FAST_RAY {
         const bool escaped = !captured && (r2n > a.r_esc2 || aff > a.max_affine);
         const bool alive = !captured && !escaped;
         float f_new = Bn * nw;
+        // Discontinuity guard (read by the hybrid kernel only): a step that crosses the disk plane registers the hit only
+        // if it does not also end the ray (render.py:2916-2934) -- with a disk wider than the escape sphere that is a hit /
+        // no-hit switch at |new_pos| = r_escape.  A crossing step that ends within the guard of a termination radius marks the lane.
+        if (f_old * f_new < 0 && (fabsf(r2n - a.r_esc2) < BHR_R2_GUARD * a.r_esc2 || fabsf(r2n - BHR_RS * BHR_RS) < BHR_R2_GUARD)) sh.unsure = 1;
+        // ... and a step that ENDS on the plane: the reference tests f_old f_new < 0, so a new_pos whose plane function
+        // rounds to exactly 0 is a crossing that no step ever registers (a black pixel inside the disk: ~1e-6 of the
+        // crossings, a dozen pixels of a 4k frame), and one a few ulps either side of 0 moves the hit into the next
+        // step (which may be the terminating one).  Only the bit-identical arithmetic reproduces these.
+        if (f_new * f_new < BHR_F_GUARD * BHR_F_GUARD * r2n) sh.unsure = 1;
         bool hit_now = false;
         if (SRC == 2) {
             if (alive) volume_segment(a, sh, to3d(u, w), to3d(nu, nw), to3d(du, dw), f_old, f_new, q_rcp(ir), r2n * q_rsq(r2n));
@@ -850,6 +851,8 @@ struct BHR_FAST_RAY {
             float hy = fmaf(hu, g1.y, hw * g2.y);
             float hr2 = fmaf(hx, hx, hy * hy);
             float hit_r = hr2 * q_rsq(hr2);
+            // the annulus test is the other switch: a crossing within the guard of either edge marks the lane
+            if (fabsf(hit_r - a.r_outer) < BHR_EDGE_GUARD * a.r_outer || fabsf(hit_r - a.r_inner) < BHR_EDGE_GUARD * a.r_inner) sh.unsure = 1;
             if (a.r_outer >= hit_r && hit_r >= a.r_inner) {   // render.py:2951
                 V3 dir3 = to3d(du, dw);                  // direction at the START of the step (render.py:2954)
                 Pending<DIFF> h;
@@ -905,7 +908,7 @@ struct BHR_FAST_RAY {
     __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, to3d(du, dw), sh); }
     __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int at) { write_pixel(a, at, done == 2, to3d(du, dw), sh); }
 };
-#endif  // fast Ray
+#endif  // BHR_MARCH_STRICT
 
 __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
     unsigned long long s = v;
@@ -924,7 +927,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // The texture kernels are held to 128 VGPRs (4 waves per SIMD): the strict arithmetic is a chain of dependent
 // exact-rounding sequences and needs the waves to cover its latency (measured at 4k with AA: 141 VGPRs / 3 waves
 // 7.6 ms, 128 / 4 waves 6.7 ms).  The binary64 Disk V2 instantiations take what they need.
-template <bool DIFF, int SRC = 0>
+// GUARD (the fast list of a hybrid march, fast object only): a lane that came within a guard band of one of the
+// algorithm's switches (Shade.unsure) does not write its pixel; it appends it to the context's fix list, which
+// march_fix_kernel (strict objects) marches again with the strict Ray.
+template <bool DIFF, int SRC = 0, bool GUARD = false>
 __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int slot) {
     const int lane = threadIdx.x & 63;
     // one 8x8 tile per wave; `slot` is its position in the launch order
@@ -962,7 +968,23 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
         int t2 = threadIdx.x;
         asm volatile("" : "+v"(t2));
         const int i2 = tx * 8 + (t2 & 7), j2 = ty * 8 + ((t2 & 63) >> 3);
-        if (tile < a.n_tiles && i2 < a.width && j2 < a.rows) ray.finish_at(a, j2 * a.width + i2);
+        const bool valid2 = tile < a.n_tiles && i2 < a.width && j2 < a.rows;
+        bool again = false;
+        if (GUARD) {
+            again = valid2 && ray.sh.unsure != 0;
+            const unsigned long long m = __ballot(again);
+            if (m) {                                   // wave-aggregated append
+                const int lane2 = t2 & 63, first = __ffsll((long long)m) - 1;
+                unsigned int base = 0;
+                if (lane2 == first) base = atomicAdd(a.fix_count, (unsigned int)__popcll(m));
+                base = __shfl(base, first, BHR_WAVE);
+                const unsigned int at = base + (unsigned int)__popcll(m & ((1ull << lane2) - 1ull));
+                if (again && at < (unsigned int)a.fix_cap) a.fix_list[at] = j2 * a.width + i2;
+                else again = false;                    // list full: the fast pixel stands
+            }
+            if (again) ray.step_count = 0;             // its steps are counted by the strict re-march
+        }
+        if (valid2 && !again) ray.finish_at(a, j2 * a.width + i2);
     }
     // a lane executes one step per loop iteration: its step count is the number of steps it executed (0: no ray)
     unsigned long long tot = wave_sum_u32((unsigned int)ray.step_count);
@@ -988,7 +1010,41 @@ __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
     march_tile_body<DIFF, SRC>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
+#if !BHR_MARCH_STRICT
+template <bool DIFF>
+__global__ __launch_bounds__(256) void march_tile_guard_kernel(BhrMarchArgs a) {
+    march_tile_body<DIFF, 0, true>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+}
+#endif
+
 #if BHR_MARCH_STRICT && BHR_MARCH_ILP
+// Second half of the hybrid march's fast list: the pixels march_tile_guard_kernel put on the fix list, 64 per wave whatever
+// tile they came from, marched with the strict Ray -- bit-identical to math_mode 1.  Launched with a grid for the list's
+// capacity; waves beyond the count the device holds exit at once.
+template <bool DIFF>
+__global__ __launch_bounds__(256) void march_fix_kernel(BhrMarchArgs a) {
+    const int wave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned int n = *a.fix_count;
+    if (n > (unsigned int)a.fix_cap) n = (unsigned int)a.fix_cap;
+    if ((unsigned int)wave * 64u >= n) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned int k = (unsigned int)wave * 64u + (unsigned int)lane;
+    const bool valid = k < n;
+    const int pix = valid ? a.fix_list[k] : 0;
+    Ray<DIFF, 0> ray;
+    ray.init(a, pix % a.width, pix / a.width);
+    if (!valid) ray.done = 4;
+    while (ray.done == 0) {
+        ray.step(a);
+        if (__ballot(ray.n_pend == 2)) ray.flush_one(a);
+    }
+    if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
+    if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
+    if (valid) ray.finish_at(a, pix);
+    const unsigned long long tot = wave_sum_u32((unsigned int)ray.step_count);
+    if (lane == 0) atomicAdd(a.ray_steps + (size_t)(blockIdx.x & (BHR_STEP_LANES - 1)) * BHR_STEP_STRIDE, tot);
+}
+
 // The ILP-scheduled object launches two kernels, each with the occupancy its register allocation should aim for
 // (A/B on fhd / 4k, isolated launches): plain texture march at 5 waves per SIMD (96 VGPRs, no spills; 0.697 -> 0.692 ms,
 // 6 waves: 0.695), AA march at 4 (128 VGPRs; 6.50 -> 6.39 ms at 4k against the default scheduler).
@@ -1015,6 +1071,7 @@ __device__ __forceinline__ void march_tiles_of_wave(const BhrMarchArgs &a) {
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void march_tile_plain_ilp(BhrMarchArgs a) { march_tiles_of_wave<false>(a); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void march_tile_aa_ilp(BhrMarchArgs a) { march_tiles_of_wave<true>(a); }
+
 #endif
 
 // ---------------------------------------------------------------------------
@@ -1190,11 +1247,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         if (flags & BHR_FORCE_HYBRID) mode = BHR_MATH_HYBRID;
         // hybrid = two launches over complementary tile lists (hybrid.hip); schedules and disk sources that have no
         // list form run strict
-        // ... and so do views with the LOD anti-aliasing: the mip level is a TRUNCATED function of the ray differentials
-        // (render.py:2987-2988, 2613), so rounding noise in the fast differentials flips the level of the pixels that sit on
-        // a level boundary -- ~300 pixels of a 4k frame by up to 0.8, which alone is 5e-4 RMSE (tools/hybrid_sweep.py)
-        const bool aa = c.anti_alias != 0 && !(flags & BHR_SKIP_DIFFERENTIALS);
-        if (mode == BHR_MATH_HYBRID && (aa || ctx->disk_source != BHR_DISK_TEXTURE || (flags & (BHR_PERSISTENT | BHR_ROW_COSTS)))) mode = BHR_MATH_STRICT;
+        if (mode == BHR_MATH_HYBRID && (ctx->disk_source != BHR_DISK_TEXTURE || (flags & (BHR_PERSISTENT | BHR_ROW_COSTS)))) mode = BHR_MATH_STRICT;
         if (mode == BHR_MATH_HYBRID) return bhr_launch_march_hybrid(ctx, cam, flags);
         if (mode == BHR_MATH_STRICT) return bhr_launch_march_strict(ctx, cam, flags);
     }
@@ -1268,6 +1321,9 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     a.tiles_x = (c.width + 7) / 8;
     a.n_tiles = a.tiles_x * ((ctx->rows + 7) / 8);
     a.n_list = a.n_tiles;
+    a.fix_count = ctx->fix_count;
+    a.fix_list = ctx->fix_list;
+    a.fix_cap = ctx->fix_cap;
     // a partial launch (ctx->part: hybrid arithmetic, pipelined row bands) marches the tiles of a caller-made list; the
     // first part records the start event and clears an untimed counter, the last part records the end event
     const bhr_march_part part = ctx->part;
@@ -1310,7 +1366,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     if (flags & BHR_PERSISTENT) BHR_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned int), ctx->stream));
     // timed launches (bhr_render) use their ring slot's events, the others the context's scalar ones
     if (first_part) BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 0] : ctx->ev[0], ctx->stream));
-    if (part.active && part.n <= 0) {
+    if (part.active && part.n <= 0 && part.repair != 2) {
         // empty list: nothing to launch
     } else if (!(flags & BHR_PERSISTENT) || a.dv2 || a.row_steps || part.active) {   // the persistent schedule has no Disk V2 / row-cost variant
         // waves per block: a block keeps its CU slot until its slowest wave has finished, so small
@@ -1331,12 +1387,21 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         } else {
             const int waves = (a.n_list + BHR_TPW - 1) / BHR_TPW;          // BHR_TPW tiles per wave
             const dim3 g((waves + wpb - 1) / wpb);
-            if (want_diff)
+            if (part.active && part.repair == 2) {                          // the fix list of a hybrid march
+                const dim3 gf((a.fix_cap / 64 + wpb - 1) / wpb);
+                if (want_diff) hipLaunchKernelGGL(march_fix_kernel<true>, gf, block, 0, ctx->stream, a);
+                else hipLaunchKernelGGL(march_fix_kernel<false>, gf, block, 0, ctx->stream, a);
+            } else if (want_diff)
                 hipLaunchKernelGGL(march_tile_aa_ilp, g, block, 0, ctx->stream, a);
             else
                 hipLaunchKernelGGL(march_tile_plain_ilp, g, block, 0, ctx->stream, a);
         }
 #else
+#if !BHR_MARCH_STRICT
+        } else if (part.active && part.repair == 1) {           // fast list of a hybrid march: guards + fix list
+            if (want_diff) hipLaunchKernelGGL(march_tile_guard_kernel<true>, grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL(march_tile_guard_kernel<false>, grid, block, 0, ctx->stream, a);
+#endif
         } else if (want_diff) {
             hipLaunchKernelGGL((march_tile_kernel<true, 0>), grid, block, 0, ctx->stream, a);
         } else {

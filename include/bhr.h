@@ -80,8 +80,12 @@ typedef struct {
  * have b within a band around b_c are marched by the STRICT kernel -- bit-identical paths, as math_mode 1 -- and all
  * other tiles by the FAST kernel, as two launches over complementary tile lists.  Pixels stay within the 1e-4 bar of
  * the reference's statements on every fixture; ray-step totals within 2e-4.  Schedules / disk sources
- * without a tile-list form (BHR_PERSISTENT, BHR_ROW_COSTS, Disk V2) run STRICT, and so do views with anti_alias = 1:
- * the mip level is a truncated function of the ray differentials, which rounding noise flips on level boundaries. */
+ * without a tile-list form (BHR_PERSISTENT, BHR_ROW_COSTS, Disk V2) run STRICT.  With anti_alias = 1 the mip level is a
+ * truncated function of the ray differentials, which rounding noise flips on level boundaries: the fast tiles' kernel
+ * then carries guards -- a lane within a guard band of a level boundary (or of another switch of the algorithm: a disk
+ * crossing in the terminating step, a step that ends on the disk plane, the disk's edges) hands its pixel to a third
+ * launch that marches it with the strict arithmetic.  BHR_HYBRID_REPAIR=1 in the environment turns the guards on for
+ * views without anti-aliasing too (17 % of the fhd frame rate for ~1e-6 of the pixels). */
 #define BHR_MATH_HYBRID 2
 
 /* Camera uniforms exactly as TaichiRenderer.render() uploads them
