@@ -227,13 +227,15 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     // truncated mip level, a disk crossing in or next to the terminating step, a step that ends on the disk plane, the
     // disk's edges -- appends its pixel to a fix list instead of writing it, and a third launch marches the listed pixels
     // with the strict arithmetic (march.hip: march_tile_guard_kernel / march_fix_kernel).  ~0.1 % of the pixels.
-    // Default: on for anti-aliased views -- the mip-level switch alone flips ~300 pixels of a 4k frame (5e-4 RMSE) -- and off
-    // without anti-aliasing, where only the rare switches remain (a step ending exactly on the disk plane: ~1e-6 of the
-    // crossings, pixels any two builds of the reference disagree on as well) and the third, dependent launch costs 17 % of
-    // the fhd frame rate (guard kernel +25 us, fix kernel 55 us: one strict wave's lifetime that nothing overlaps).
+    // Default: on for anti-aliased views -- the mip-level switch alone flips ~300 pixels of a 4k frame (5e-4 RMSE) -- and for
+    // TILTED disks: the plane function z - y tan(tilt) of a point on the plane is then a difference of O(1) numbers, it
+    // rounds to exactly 0 for ~1e-6 of the crossings, and the reference's `f_old f_new < 0` never registers those (12 pixels
+    // of a 4k tilt-25 frame by a whole disk colour: 6.5e-4 RMSE).  With tilt 0 the function is z itself, which has full
+    // relative precision at the plane: no exact zeros, and the third, dependent launch would cost 17 % of the fhd frame
+    // rate (guard kernel +25 us, fix kernel 55 us: one strict wave's lifetime that nothing overlaps) -- off.
     // BHR_HYBRID_REPAIR=1 / 0 forces it on / off.
     const bool aa = ctx->cfg.anti_alias != 0 && !(flags & BHR_SKIP_DIFFERENTIALS);
-    bool repair = aa;
+    bool repair = aa || ctx->cfg.disk_tilt_deg != 0.0f;
     if (const char *e = getenv("BHR_HYBRID_REPAIR")) repair = atoi(e) != 0;
     const int slot_k = ctx->active_slot >= 0 && ctx->active_slot < BHR_MAX_FRAME_SLOTS ? ctx->active_slot : 0;
     FixList &fx = h->fix[slot_k];

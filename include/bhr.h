@@ -84,8 +84,9 @@ typedef struct {
  * truncated function of the ray differentials, which rounding noise flips on level boundaries: the fast tiles' kernel
  * then carries guards -- a lane within a guard band of a level boundary (or of another switch of the algorithm: a disk
  * crossing in the terminating step, a step that ends on the disk plane, the disk's edges) hands its pixel to a third
- * launch that marches it with the strict arithmetic.  BHR_HYBRID_REPAIR=1 in the environment turns the guards on for
- * views without anti-aliasing too (17 % of the fhd frame rate for ~1e-6 of the pixels). */
+ * launch that marches it with the strict arithmetic.  The guards are also on for tilted disks (the plane function of a
+ * step that ends on a tilted plane rounds to exactly 0 for ~1e-6 of the crossings, which the reference's sign test never
+ * registers); with tilt 0 and no anti-aliasing they are off (BHR_HYBRID_REPAIR=1 / 0 in the environment forces them). */
 #define BHR_MATH_HYBRID 2
 
 /* Camera uniforms exactly as TaichiRenderer.render() uploads them

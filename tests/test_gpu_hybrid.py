@@ -170,3 +170,34 @@ def test_hybrid_with_lod_anti_aliasing_4k(hip_lib):
         assert (e <= MARGIN).all(), (k, e)
     d = np.abs(lay["hybrid"]["final"] - lay["strict"]["final"]).max(axis=2)
     assert d.max() <= 0.05 and (d > 1e-3).sum() <= 100, (float(d.max()), int((d > 1e-3).sum()))   # measured: 0.014, 30 of 8.3 M
+
+
+def test_hybrid_guards_catch_the_algorithm_s_own_switches(hip_lib, capsys, monkeypatch):
+    """Far from the photon ring the reference's algorithm still has switches that only the bit-identical arithmetic
+    reproduces: a step whose new_pos has a plane function of exactly 0 is a crossing no step ever registers (the test is
+    f_old f_new < 0: a black pixel inside the disk), a crossing in the terminating step registers no hit, the annulus test.
+    ~1e-6 of the crossings of a TILTED disk -- but each is a whole disk colour.  With the guards on (the default for tilted
+    disks and for anti-aliased views) those lanes are re-marched strict: no pixel of a 4k tilt-25 frame differs from strict
+    by more than 0.05 (measured 0.0046); with the guards forced off the frame shows a dozen such pixels (12, max 0.79: printed,
+    they are the reference's own discontinuities -- any two builds of it disagree there too)."""
+    import bench
+    from bhr_amd import _lib, workloads
+    wl = dict(bench.WORKLOADS["4k"], anti_alias="disabled", lens_flare=False)
+    r, _, _, _ = workloads.make_scene(wl, frame_slots=1)
+    r.render_async(wl["cam_pos"], wl["fov"], math="strict")
+    strict = r.read_layer(_lib.LAYER_DISK)
+    out = {}
+    for rep in ("default", "0"):
+        if rep == "default":
+            monkeypatch.delenv("BHR_HYBRID_REPAIR", raising=False)
+        else:
+            monkeypatch.setenv("BHR_HYBRID_REPAIR", rep)
+        r.render_async(wl["cam_pos"], wl["fov"], math="hybrid")
+        disk = r.read_layer(_lib.LAYER_DISK)
+        d = np.abs(disk - strict).max(axis=2)
+        out[rep] = (float(d.max()), int((d > 0.05).sum()), float(_rmse_c(disk, strict).max()))
+    r.close()
+    with capsys.disabled():
+        print(f"\n[hybrid guards] 4k tilt 25, AA off, disk layer vs strict (max, pixels > 0.05, per-channel RMSE): guards on {out['default']}, off {out['0']}")
+    assert out["default"][0] <= 0.05 and out["default"][1] == 0, out
+    assert out["default"][2] <= 5e-5 and out["0"][2] <= 1e-3, out

@@ -76,8 +76,11 @@ def test_kernels_vs_reference_statements_f64(name, math, hip_lib):
     assert abs(c["ray_steps"] - steps64) <= 2e-4 * steps64
     for k in ("bg", "disk", "blur", "final"):
         e = float(_rmse_c(lay[k], _ref_layer(g, "f64", k)).max())
-        bar = max(NORTH_STAR, 1.5 * _f32_vs_f64(g, k))
-        assert e <= bar, f"{name}/{math}/{k}: RMSE {e:.3g} > {bar:.3g} (reference f32 vs f64: {_f32_vs_f64(g, k):.3g})"
+        # the plain north-star bar on every view and layer, for both arithmetics (round 2 allowed 1.5 x the reference's own
+        # f32-vs-f64 distance where that exceeded it; it never does on these views: tools/fast_bars.py measures the fast
+        # kernel at 3.8e-7 ... 4.9e-5 -- worst: `inside`, camera in the annulus -- against a reference f32-vs-f64 distance of
+        # 3e-7 ... 3e-5)
+        assert e <= NORTH_STAR, f"{name}/{math}/{k}: RMSE {e:.3g} > {NORTH_STAR:g} (reference f32 vs f64: {_f32_vs_f64(g, k):.3g})"
 
 
 def test_reference_f32_vs_f64_distance_is_what_the_bar_assumes():
