@@ -130,9 +130,20 @@ __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f),
 __global__ __launch_bounds__(256) void background_kernel(float *__restrict__ comp, int n_r, int n_phi, int az_freq,
                                                          float az_shear, float r_inner, float r_outer, float t) {
     __shared__ perm_t perm[1024];
-    load_perm(perm);
-    const int phi_i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float row_pow[2];
     const int ri = blockIdx.y;
+    // The libm calls are evaluated in binary64 and rounded once -- what the reference's statements evaluate to under
+    // tests/golden/ti_shim.py, and within a few 1e-9 of cases the correctly rounded f32 value.  ocml's f32 sin / cos /
+    // pow are 1-2 ulp off, and an ulp of cos(phi) is multiplied by up to 1600 before it indexes the noise lattice: the
+    // turbulence planes then differed from the reference-statement fixtures by 3e-3 at the 99th percentile (round 2's
+    // loosest bar).  The two powers depend on the row only: one thread per block computes them.
+    if (threadIdx.x == 0) {
+        const float r0 = (float)ri / (float)n_r;
+        row_pow[0] = (float)pow((double)fmaxf(1.0f - r0, 0.0f), (double)1.3f);
+        row_pow[1] = (float)pow((double)r0, (double)1.2f);
+    }
+    load_perm(perm);                               // ends with __syncthreads()
+    const int phi_i = blockIdx.x * blockDim.x + threadIdx.x;
     if (phi_i >= n_phi) return;
     const size_t plane = (size_t)n_r * n_phi;
     const size_t q = (size_t)ri * n_phi + phi_i;
@@ -143,10 +154,10 @@ __global__ __launch_bounds__(256) void background_kernel(float *__restrict__ com
     float r_phys = r_inner + (r_outer - r_inner) * r;
     float omega = sqrtf(0.5f / (r_phys * r_phys * r_phys + 1e-6f));
     float phi_rot = phi + omega * t;
-    float cx = cosf(phi_rot);
-    float cy = sinf(phi_rot);
+    float cx = (float)cos((double)phi_rot);
+    float cy = (float)sin((double)phi_rot);
 
-    float decay = powf(fmaxf(1.0f - r, 0.0f), 1.3f);
+    float decay = row_pow[0];
     float tb_noise = clamp01(0.5f + 0.5f * fbm3<4>(perm, cx * 8.0f, cy * 8.0f, r * 8.0f + t * 0.05f, 0.6f, 2.0f));
     comp[0 * plane + q] = decay * (0.85f + 0.15f * tb_noise) * 0.25f;
     comp[1 * plane + q] = 0.0f;
@@ -162,8 +173,8 @@ __global__ __launch_bounds__(256) void background_kernel(float *__restrict__ com
     comp[3 * plane + q] = turb;
     comp[4 * plane + q] = 0.05f * turb;
 
-    float shear = powf(r, 1.2f) * az_shear;
-    float az_wave = 0.5f + 0.5f * sinf((phi_rot + shear) * (float)az_freq);
+    float shear = row_pow[1] * az_shear;
+    float az_wave = 0.5f + 0.5f * (float)sin((double)((phi_rot + shear) * (float)az_freq));
     float az_n = clamp01(0.5f + 0.5f * fbm3<3>(perm, cx * 3.0f, cy * 3.0f, r * 3.0f + t * 0.04f, 0.5f, 2.0f));
     comp[11 * plane + q] = az_wave * az_n;
 

@@ -144,13 +144,13 @@ def test_background_vs_reference_statements(t, texg, hip_lib):
     hip.generate_background(t)
     got = hip.read_comp()
     hip.close()
-    # ocml sin/cos/pow vs correctly rounded values, amplified by the x800 noise frequency and the noise's own
-    # discontinuities at cell faces (0.6 kernel radius): robust statistics for planes 3 and 12, tight elsewhere
-    for idx in (0, 4, 11):
-        assert np.abs(got[idx] - ref[idx]).max() <= 2e-4, (idx, np.abs(got[idx] - ref[idx]).max())
-    for idx in (3, 12):
+    # Round 3: the kernel evaluates its sin / cos / pow in binary64 and rounds once, as the reference's statements do under
+    # the shim -- every plane within 1.2e-7 (1 ulp of the sums; 93-100 % of the texels bit-identical) at every t.  (Round 2,
+    # ocml's f32 functions: an ulp of cos(phi) x 1600 in the noise coordinates, planes 3 and 12 only held to median 2e-5 /
+    # q99 3e-3 -- the loosest bar of the suite.)
+    for idx in (0, 3, 4, 11, 12):
         d = np.abs(got[idx] - ref[idx])
-        assert np.median(d) <= 2e-5 and np.quantile(d, 0.99) <= 3e-3, (idx, np.median(d), d.max())
+        assert d.max() <= 5e-7, (idx, d.max(), np.median(d))
     assert not got[1].any() and not got[2].any() and not got[5:11].any()
 
 
@@ -194,10 +194,9 @@ def test_e2e_frame_on_the_reference_s_texture(hip_lib):
 
 def test_e2e_whole_pipeline_vs_the_reference_s_render_image(hip_lib, capsys):
     """`render_image` end to end on the device -- skybox, entity lifecycle, background / compose / mip kernels, march,
-    bloom -- against the reference's render_image output.  The disk texture differs from the reference's by libm
-    rounding in the background generator (sin/cos/pow feeding noise lookups at frequencies up to 800: texels
-    move by up to ~1e-4 here), the frame inherits that through the bilinear lookups.  Measured: texture max 9.8e-5,
-    frame per-channel RMSE 1.3-2.0e-6 -- 50x inside the north star's 1e-4."""
+    bloom -- against the reference's render_image output.  Measured (round 3): texture max 4.2e-7, compose statistics
+    equal, frame per-channel RMSE 2.3-3.3e-7 -- 300x inside the north star's 1e-4.  (Round 2: the background generator's
+    f32 sin / cos / pow moved texels by up to ~1e-4 through noise look-ups at frequencies up to 1600; frame 1.3-2.0e-6.)"""
     import hashlib
     from bhr_amd import HipRenderer, drivers
     from test_reference_kernels import E2E_KW, load_e2e
@@ -216,10 +215,12 @@ def test_e2e_whole_pipeline_vs_the_reference_s_render_image(hip_lib, capsys):
               f"tests/e2e_baseline.txt {g['baseline_md5']}")
         print(f"[e2e] texture: max {dt.max():.3g} median {np.median(dt):.3g} p99.9 {np.quantile(dt, 0.999):.3g}; "
               f"stats {stats} vs {g['stats']}; frame RMSE {e}, max {np.abs(img - g['final']).max():.3g}")
-    np.testing.assert_allclose(stats, g["stats"], rtol=2e-3)
-    np.testing.assert_allclose(row_stats, g["row_stats"], rtol=5e-3, atol=1e-4)
-    assert np.median(dt) <= 1e-5 and dt.max() <= 1e-3          # measured: median 2.8e-6, max 9.8e-5
-    assert (e <= 1e-5).all() and (e <= NORTH_STAR).all(), e    # measured 1.3-2.0e-6; north star 1e-4
+    np.testing.assert_allclose(stats, g["stats"], rtol=1e-5)
+    np.testing.assert_allclose(row_stats, g["row_stats"], rtol=1e-4, atol=1e-6)
+    # round 3 (background kernel's libm calls in binary64, rounded once): texture max 4.2e-7, median 0, statistics equal to
+    # the printed digits, frame RMSE 2.3-3.3e-7.  (Round 2: texture max 9.8e-5, frame 1.3-2.0e-6.)  North star: 1e-4.
+    assert np.median(dt) <= 1e-7 and dt.max() <= 5e-6, (np.median(dt), dt.max())
+    assert (e <= 2e-6).all(), e
 
 
 def test_video_loop_vs_the_reference_s_video_loop(hip_lib, capsys):
@@ -251,8 +252,8 @@ def test_video_loop_vs_the_reference_s_video_loop(hip_lib, capsys):
         e = _rmse_c(img, g[f"final_{frame}"])
         lines.append(f"[video] frame {frame}: texture max {dtx.max():.3g} median {np.median(dtx):.3g}; frame RMSE {e}, "
                      f"max {np.abs(img - g[f'final_{frame}']).max():.3g}")
-        assert np.median(dtx) <= 1e-5 and dtx.max() <= 2e-3, (frame, np.median(dtx), dtx.max())
-        assert (e <= 2e-5).all() and (e <= NORTH_STAR).all(), (frame, e)
+        assert np.median(dtx) <= 1e-7 and dtx.max() <= 5e-6, (frame, np.median(dtx), dtx.max())   # measured: max 4.2e-7 (round 2: 1.3e-4)
+        assert (e <= 2e-6).all(), (frame, e)                                                        # measured 2.6-4.1e-7 (round 2: 1.3-2.4e-6)
     r.close()
     with capsys.disabled():
         print("\n" + "\n".join(lines))
