@@ -74,9 +74,10 @@ def parse():
                     help="march arithmetic of the headline (default hybrid: strict on the tiles whose rays pass near the photon "
                          "sphere, fast elsewhere; certified within the north-star tolerance by tests/test_gpu_hybrid.py).  The other "
                          "two are timed beside it as `other_math`")
-    ap.add_argument("--spin-up-ms", type=float, default=60.0,
+    ap.add_argument("--spin-up-ms", type=float, default=300.0,
                     help="un-timed frames rendered for this long BEFORE the --warmup steps: the scene set-up leaves the GPU idle "
-                         "and its clocks low, and they take ~20 ms of load to come back (tools/exp_bench_ramp.py)")
+                         "and its clocks low; the march reaches its steady duration after ~25 ms of load and the last 3 % after "
+                         "~0.3 s (tools/exp_bench_ramp.py; sweep 0 / 60 / 300 / 1000 ms in DESIGN section 5)")
     return ap.parse_args()
 
 
@@ -350,11 +351,19 @@ def main():
     renderer, sky, tex, scene_note = workloads.make_scene(wl, device_index=local_rank, math=args.math,
                                                           frame_slots=args.frame_slots)
 
-    def barrier():
+    stamps = {}
+
+    def barrier(tag=None):
+        ts = [time.perf_counter()]
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        renderer.sync()
+        ts.append(time.perf_counter())
+        renderer.sync()                 # the renderer's own streams (a stream wait + hipStreamSynchronize) ...
+        ts.append(time.perf_counter())
+        torch.cuda.synchronize()        # ... then torch's device-wide synchronise
+        ts.append(time.perf_counter())
+        if tag:
+            stamps[tag] = ts
 
     # frames sharded round-robin over ranks (configs[4]); the camera is the static default pov
     compaction = args.persistent
@@ -382,8 +391,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         renderer.render_async(wl["cam_pos"], wl["fov"], compaction=compaction, lens_flare=flare)
-    barrier()
+    barrier("close")
     elapsed = time.perf_counter() - t0
+    tc = stamps["close"]
+    region_ms = {"host_submit": (tc[0] - t0) * 1e3, "dist_barrier": (tc[1] - tc[0]) * 1e3,
+                 "renderer_sync": (tc[2] - tc[1]) * 1e3, "torch_synchronize": (tc[3] - tc[2]) * 1e3}
 
     c = renderer.counters()
     steps_per_frame = c["ray_steps"]
@@ -509,6 +521,8 @@ def main():
             "kernel_ms_in_timed_region": dict(overlapped, march_busy_ms=c["march_busy_ms"], span_ms=c["span_ms"],
                                               note="event brackets of overlapping launches (two frame slots): each covers time shared "
                                                    "with the other frame's kernels; march_busy_ms = union of the march intervals"),
+            "timed_region_ms": dict(region_ms, total=elapsed * 1e3,
+                                    note="host stamps: the K submissions, then the closing bracket's parts in the order they run"),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "march", "algorithmic_bytes_per_launch": alg_bytes},
