@@ -62,17 +62,18 @@ int32_t alloc_slot(bhr_ctx *ctx, int k) {
     int32_t rc = BHR_OK;
     if ((rc = dev_alloc(&f.d_bg, px3)) || (rc = dev_alloc(&f.d_disk, px3)) || (rc = dev_alloc(&f.d_blur, px3)) ||
         (rc = dev_alloc(&f.d_final, px3)) || (rc = dev_alloc(&f.d_final_u8, px3)) ||
-        (rc = dev_alloc(&f.d_hblur, 3 * (rows + 2 * R) * W)) || (rc = dev_alloc(&f.d_queue, 1))) {
-        void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur, f.d_queue};   // a later retry starts clean
+        (rc = dev_alloc(&f.d_hblur_base, 3 * (rows + 2 * R) * W + 2 * BHR_HBLUR_PAD_ROWS * W)) || (rc = dev_alloc(&f.d_queue, 1))) {
+        void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur_base, f.d_queue};   // a later retry starts clean
         for (void *b : bufs)
             if (b) (void)hipFree(b);
-        f.d_bg = f.d_disk = f.d_blur = f.d_final = f.d_hblur = nullptr;
+        f.d_bg = f.d_disk = f.d_blur = f.d_final = f.d_hblur = f.d_hblur_base = nullptr;
         f.d_final_u8 = nullptr;
         f.d_queue = nullptr;
         return rc;
     }
     // the halo rows of the H-blur buffer outside the image stay zero for the life of the context
-    BHR_HIP(hipMemsetAsync(f.d_hblur, 0, 3 * (rows + 2 * R) * W * sizeof(float), ctx->scene_stream));
+    f.d_hblur = f.d_hblur_base + BHR_HBLUR_PAD_ROWS * W;
+    BHR_HIP(hipMemsetAsync(f.d_hblur_base, 0, (3 * (rows + 2 * R) * W + 2 * BHR_HBLUR_PAD_ROWS * W) * sizeof(float), ctx->scene_stream));
     BHR_HIP(hipStreamSynchronize(ctx->scene_stream));
     f.allocated = 1;
     return BHR_OK;
@@ -80,7 +81,7 @@ int32_t alloc_slot(bhr_ctx *ctx, int k) {
 
 void free_slot(bhr_ctx *ctx, int k) {
     bhr_frame_slot &f = ctx->slots[k];
-    void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur, f.d_queue,
+    void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur_base, f.d_queue,
                     f.d_glow_hw, f.d_glow_wh, f.d_flare_c0, f.d_flare_c12, f.d_flare_sums};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -376,7 +377,7 @@ void bhr_destroy(bhr_ctx *ctx) {
     if (ctx->scene_ev) (void)hipEventDestroy(ctx->scene_ev);
     void *bufs[] = {ctx->d_skybox,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_noise_in,
-                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_dv2_params,
+                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_wsplit, ctx->d_dv2_params,
                     ctx->d_flare_prog, ctx->d_tile_order, ctx->d_row_steps, ctx->d_gather};   // the flare's per-frame scratch belongs to the slots
     for (void *b : bufs)
         if (b) (void)hipFree(b);

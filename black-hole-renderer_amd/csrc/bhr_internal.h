@@ -25,6 +25,9 @@
 // Ray-step counters: every wave adds its count with one atomic.  32 400 atomics to ONE address serialise in
 // the memory system and put a floor of 0.45 ms under an fhd launch (measured; the fast march spends 0.36 ms);
 // a counter is therefore a cell of 128 lanes, 256 bytes apart, indexed by block, summed when read.
+// rows of zeros in front of and behind the (3, rows + 2R, W) H-blur planes: the bf16 V pass walks input rows in chunks
+// aligned to global multiples of 16 and reads up to 15 rows past either end (zero weights; bloom.hip)
+#define BHR_HBLUR_PAD_ROWS 16
 #define BHR_STEP_LANES 128
 #define BHR_STEP_STRIDE 32          // in u64 words
 #define BHR_STEP_CELL (BHR_STEP_LANES * BHR_STEP_STRIDE)
@@ -106,6 +109,7 @@ struct bhr_march_part {
 struct bhr_frame_slot {
     hipStream_t stream;
     float *d_bg, *d_disk, *d_hblur, *d_blur, *d_final;
+    float *d_hblur_base;       // the allocation d_hblur points BHR_HBLUR_PAD_ROWS rows into (zero rows in front of plane 0 and behind plane 2)
     uint8_t *d_final_u8;
     unsigned int *d_queue;
     // lens flare scratch of the frame (flare.hip): glow rows, their transpose, chunk sums, the three frame sums
@@ -176,6 +180,8 @@ struct bhr_ctx {
     uint8_t *d_final_u8;       // (rows, W, 3)
     float *d_wtab;             // bloom weights (3, R + pad)
     float *d_wext;             // unfolded weights (3, 2 R4 + 8)
+    unsigned short *d_wsplit;  // bf16 x 3 weight table, 9 parts x 8 shifted copies (bloom.hip: bloom_wsplit_kernel)
+    int32_t bloom_split;       // 1: the post-pass of the current frame runs on the bf16 matrix cores (fast / hybrid arithmetic)
     float *d_wsum_h;           // (3, W)
     float *d_wsum_v;           // (3, H)
     int32_t bloom_R, bloom_ready;

@@ -602,14 +602,337 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T == 1 ? 4 
     }
 }
 
+// ---- both passes on the bf16 matrix cores, f32 operands split three ways ---------------------------------------------
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the f32 form.  An f32 value is EXACTLY the sum of three bf16 values
+// (its 24 significand bits cut 8 + 8 + 8 by truncation: x = hi + mid + lo, every difference exact), so the product of two
+// f32 values is the sum of nine bf16 products; the six of relative order >= 2^-16 (hi hi, hi mid, mid hi, hi lo, lo hi,
+// mid mid) leave out 2^-23 of the result -- the rounding of ONE f32 operation, where the f32 chain rounds once per tap.
+// Six MFMAs of depth 16 instead of eight of depth 2: 2.7x the f32 matrix (= vector) peak.  Products are exact in the
+// MFMA, sums are kept in f32.  Not bit-identical to the f32 kernels (tools/exp_bloom.py: 2-3e-7 on layers of order 1);
+// selected for the fast and hybrid arithmetic, never for strict (bhr_ctx::bloom_split).
+//   pixels   : loaded as f32, cut in registers (4 VALU per value + 1.5 to pack pairs), shared by the wave's T tiles;
+//   weights  : the Toeplitz operand w[|i - y|] is eight consecutive entries of the zero-padded table starting at an index
+//              that depends on the lane -- the table sits in LDS as three bf16 parts x EIGHT copies shifted by 0..7
+//              entries, so that every lane's window is one aligned ds_read_b128 (copies 32 B apart modulo 256: the sixteen
+//              lanes of a pass hit sixteen different bank groups); built once per context in global memory
+//              (bloom_wsplit_kernel), copied per block.
+// K chunks are aligned to GLOBAL multiples of 16 rows / pixels, so an output's operands meet the same MFMA slots whatever
+// the tiling: row blocks, chunks and whole frames give the same bits (tests/test_gpu_multidevice.py).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int SPLIT_TMAX = 2;          // the table is padded for up to 2 stacked / adjacent 32-wide tiles per wave
+
+__host__ __device__ inline int wsplit_off(int R) { return R + 32 * SPLIT_TMAX + 24; }
+__host__ __device__ inline int wsplit_nw(int R) { return (wsplit_off(R) + R + 32 * SPLIT_TMAX + 24 + 7) & ~7; }
+__host__ __device__ inline int wsplit_cs(int R) {       // bytes between two shifted copies: >= 2 NW, == 32 modulo 256
+    const int need = 2 * wsplit_nw(R);
+    return ((need - 32 + 255) / 256) * 256 + 32;
+}
+
+__device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l) {
+    const unsigned u = __float_as_uint(x);
+    h = u & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xffff0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));      // at most 8 significant bits left: its upper half is all of it
+}
+
+// out[((c * 3 + part) * 8 + shift) * CS / 2 + n] = part of w_c[|n + shift - OFF|] (zero beyond R), n + shift < NW
+__global__ void bloom_wsplit_kernel(const float *wtab, unsigned short *out, int R) {
+    const int OFF = wsplit_off(R), NW = wsplit_nw(R), CS2 = wsplit_cs(R) / 2, stride = R + 1 + WPAD;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 3 * NW) return;
+    const int c = k / NW, idx = k - c * NW;
+    int d = idx - OFF;
+    d = d < 0 ? -d : d;
+    const float w = d <= R ? wtab[c * stride + d] : 0.0f;
+    unsigned part[3];
+    split3(w, part[0], part[1], part[2]);
+    for (int p = 0; p < 3; ++p)
+        for (int sh = 0; sh < 8; ++sh) {
+            const int n = idx - sh;
+            if (n >= 0) out[(size_t)((c * 3 + p) * 8 + sh) * CS2 + n] = (unsigned short)(part[p] >> 16);
+        }
+}
+
+// eight f32 values -> three fragments of eight bf16 (k = element index)
+// `sel` = 0x07060302 held in a VGPR by the caller: v_perm_b32 with an SGPR selector issues at half rate
+// (profiles/r03_valu_sgpr_operand_ubench.txt)
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 &hi, u32x4 &mid, u32x4 &lo, unsigned sel) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(x[j], h[j], m[j], l[j]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {          // dword q = elements 2q (low half) and 2q + 1 (high half): their upper 16 bits
+        hi[q] = __builtin_amdgcn_perm(h[2 * q + 1], h[2 * q], sel);
+        mid[q] = __builtin_amdgcn_perm(m[2 * q + 1], m[2 * q], sel);
+        lo[q] = __builtin_amdgcn_perm(l[2 * q + 1], l[2 * q], sel);
+    }
+}
+
+// acc += sum over the chunk's 16 k of (pixel part) x (weight part), the six products in ascending order of magnitude
+#define BHR_SPLIT_MFMA6(ACC, PH, PM, PL, WH, WM, WL, PIX_IS_A)                                                                     \
+    do {                                                                                                                           \
+        const bf16x8 mq_ph_ = __builtin_bit_cast(bf16x8, PH), mq_pm_ = __builtin_bit_cast(bf16x8, PM), mq_pl_ = __builtin_bit_cast(bf16x8, PL); \
+        const bf16x8 mq_wh_ = __builtin_bit_cast(bf16x8, WH), mq_wm_ = __builtin_bit_cast(bf16x8, WM), mq_wl_ = __builtin_bit_cast(bf16x8, WL); \
+        if (PIX_IS_A) {                                                                                                            \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_pl_, mq_wh_, ACC, 0, 0, 0);                                                 \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_ph_, mq_wl_, ACC, 0, 0, 0);                                                 \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_pm_, mq_wm_, ACC, 0, 0, 0);                                                 \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_pm_, mq_wh_, ACC, 0, 0, 0);                                                 \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_ph_, mq_wm_, ACC, 0, 0, 0);                                                 \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_ph_, mq_wh_, ACC, 0, 0, 0);                                                 \
+        } else {                                                                                                                   \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_wh_, mq_pl_, ACC, 0, 0, 0);                                                 \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_wl_, mq_ph_, ACC, 0, 0, 0);                                                 \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_wm_, mq_pm_, ACC, 0, 0, 0);                                                 \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_wh_, mq_pm_, ACC, 0, 0, 0);                                                 \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_wm_, mq_ph_, ACC, 0, 0, 0);                                                 \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mq_wh_, mq_ph_, ACC, 0, 0, 0);                                                 \
+        }                                                                                                                          \
+    } while (0)
+
+// copy the context's split table (9 x 8 copies of CS bytes) into LDS
+__device__ __forceinline__ void stage_wsplit(unsigned char *lds, const unsigned short *__restrict__ wsplit, int R) {
+    const int n16 = 72 * wsplit_cs(R) / 16;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(wsplit);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
+    for (int k = threadIdx.x; k < n16; k += 256) dst[k] = src[k];
+}
+
+// V pass.  A wave owns T stacked 32-row tiles of one 32-column strip; grid (ceil(W / 128), ceil(rows / 32 T)).
+template <int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bloom_v_bf16_kernel(const float *__restrict__ hblur, const float *__restrict__ bg,
+                                                           const float *__restrict__ disk, float *__restrict__ blur_out,
+                                                           float *__restrict__ final_out, const unsigned short *__restrict__ wsplit,
+                                                           const float *__restrict__ wsum_v, int W, int H, int row0, int rows,
+                                                           int R, int with_bloom, unsigned long long *__restrict__ zero_cell,
+                                                           int row_begin, int row_end, uint8_t *__restrict__ u8_out) {
+    static_assert(T <= SPLIT_TMAX, "table padding");
+    if (zero_cell && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < BHR_STEP_LANES)
+        zero_cell[(size_t)threadIdx.x * BHR_STEP_STRIDE] = 0ull;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
+    if (with_bloom) stage_wsplit(lds_b, wsplit, R);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xs = (blockIdx.x * 4 + wave) * 32;
+    const int y0 = row_begin + blockIdx.y * (32 * T);
+    if (xs >= W) return;
+    const int n = lane & 31, kh = lane >> 5, x = xs + n;
+    const bool x_ok = x < W;
+
+    f32x16 acc[3][T];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.0f;
+
+    if (with_bloom) {
+        const int OFF = wsplit_off(R), CS = wsplit_cs(R);
+        const size_t plane = (size_t)(rows + 2 * R) * W;
+        const int yg0 = y0 + row0;                                           // global row of the wave's first output
+        const int ig_first = (yg0 - R) & ~15, ig_last = yg0 + 32 * T - 1 + R;   // chunk starts: global multiples of 16
+        // window start of tile 0 in chunk ig: OFF + ig - yg0 + 8 kh - n; its residue modulo 8 picks the shifted copy
+        const int s0 = OFF - yg0 + 8 * kh - n + ig_first;                    // >= 0 by the table's padding
+        const int ph = s0 & 7;
+        const unsigned char *wl = lds_b + ph * CS + (s0 - ph) * 2;          // advances 32 bytes per chunk, -64 per tile
+        const int part = 8 * CS;                                             // bytes between two parts, 3 parts per channel
+        // Chunks are whole inside or whole outside the image (H is a multiple of 16: the launcher's condition): those outside
+        // are skipped taps and are not walked.  A chunk inside the image may reach up to 15 rows past what this context's
+        // planes hold: rows outside the band of every output the wave stores (zero weights), read from the neighbouring
+        // plane or from the BHR_HBLUR_PAD_ROWS zero rows around the allocation -- finite values, no predicate on any load.
+        // Addresses: a wave-uniform row pointer (scalar registers, scalar arithmetic) + one per-lane offset.
+        const unsigned lane_off = (unsigned)(8 * kh) * (unsigned)W + (x_ok ? x : W - 1);   // a column past the image: garbage nobody stores
+        // first and last chunk start walked: inside the image, and not past the chunk that holds the last row of the planes (a
+        // tile that overhangs the row block computes rows nobody stores from whatever the chunks it does walk contain)
+        const int ig_a = max(ig_first, 0), ig_b = min(min(ig_last, H - 16), (row0 + rows + R - 1) & ~15);
+        wl += 2 * (ig_a - ig_first);
+        auto load = [&](int ig, float (&b)[3][8]) {
+            const float *rowp = hblur + ((ptrdiff_t)(min(ig, ig_b) - row0 + R)) * W;     // prefetch past the last chunk: a re-read
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[c][j] = (rowp + c * plane + (size_t)j * W)[lane_off];
+        };
+        unsigned sel = 0x07060302u;
+        asm volatile("" : "+v"(sel));
+        auto chunk = [&](const float (&b)[3][8], const unsigned char *wq) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                u32x4 ph_, pm_, pl_;
+                split8(b[c], ph_, pm_, pl_, sel);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const unsigned char *q = wq + (3 * c) * part - 64 * t;
+                    const u32x4 wh = *reinterpret_cast<const u32x4 *>(q);
+                    const u32x4 wm = *reinterpret_cast<const u32x4 *>(q + part);
+                    const u32x4 wlo = *reinterpret_cast<const u32x4 *>(q + 2 * part);
+                    BHR_SPLIT_MFMA6(acc[c][t], ph_, pm_, pl_, wh, wm, wlo, false);
+                }
+            }
+        };
+        // two chunk buffers, alternating: the loads of chunk k + 1 are issued and pinned (sched_barrier) in front of the
+        // MFMAs of chunk k, which cover their latency
+        float b0[3][8], b1[3][8];
+        load(ig_a, b0);
+        for (int ig = ig_a; ig <= ig_b;) {
+            load(ig + 16, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk(b0, wl);
+            ig += 16; wl += 32;
+            if (ig > ig_b) break;
+            load(ig + 16, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk(b1, wl);
+            ig += 16; wl += 32;
+        }
+    }
+    if (!x_ok) return;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int yl = y0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (yl >= row_end) continue;
+            const int yg = yl + row0;
+            float b0 = 0, b1 = 0, b2 = 0;
+            if (with_bloom) {
+                b0 = acc[0][t][r] / wsum_v[yg];
+                b1 = acc[1][t][r] / wsum_v[H + yg];
+                b2 = acc[2][t][r] / wsum_v[2 * H + yg];
+            }
+            const size_t o = ((size_t)yl * W + x) * 3;
+            blur_out[o + 0] = b0;
+            blur_out[o + 1] = b1;
+            blur_out[o + 2] = b2;
+            const float f0 = fminf(fmaxf(bg[o + 0] + disk[o + 0] + b0, 0.0f), 1.0f);
+            const float f1 = fminf(fmaxf(bg[o + 1] + disk[o + 1] + b1, 0.0f), 1.0f);
+            const float f2 = fminf(fmaxf(bg[o + 2] + disk[o + 2] + b2, 0.0f), 1.0f);
+            final_out[o + 0] = f0;
+            final_out[o + 1] = f1;
+            final_out[o + 2] = f2;
+            if (u8_out) {
+                u8_out[o + 0] = (uint8_t)(int)(f0 * 255.0f);
+                u8_out[o + 1] = (uint8_t)(int)(f1 * 255.0f);
+                u8_out[o + 2] = (uint8_t)(int)(f2 * 255.0f);
+            }
+        }
+    }
+}
+
+// H pass.  A wave owns T adjacent 32-pixel output tiles of 32 rows; grid (ceil(W / 32 T), ceil(rows / 128)).
+template <int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bloom_h_bf16_kernel(const float *__restrict__ disk, float *__restrict__ hblur,
+                                                           const unsigned short *__restrict__ wsplit, const float *__restrict__ wsum_h,
+                                                           int W, int rows, int R, int row_begin, int row_end) {
+    static_assert(T <= SPLIT_TMAX, "table padding");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
+    stage_wsplit(lds_b, wsplit, R);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = blockIdx.x * (32 * T);
+    const int y0 = row_begin + (blockIdx.y * 4 + wave) * 32;
+    if (y0 >= row_end) return;
+    const int n = lane & 31, kh = lane >> 5, yl = y0 + n;
+    const bool y_ok = yl < row_end;
+
+    f32x16 acc[3][T];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.0f;
+
+    const int OFF = wsplit_off(R), CS = wsplit_cs(R);
+    const int ig_first = (x0 - R) & ~15, ig_last = x0 + 32 * T - 1 + R;
+    const int s0 = OFF - x0 + 8 * kh - n + ig_first;
+    const int ph = s0 & 7;
+    const unsigned char *wl = lds_b + ph * CS + (s0 - ph) * 2;
+    const int part = 8 * CS;
+    // W is a multiple of 16 (the launcher's condition): a chunk lies whole inside the row or whole outside it, and those
+    // outside are skipped taps that are not walked; rows are 16-byte aligned.  A row past the block reads row y0 and is
+    // never stored.  The lane's 8 pixels x 3 channels of a chunk are 24 consecutive floats of its row.
+    const int ig_a = max(ig_first, 0), ig_b = min(ig_last, W - 16);
+    wl += 2 * (ig_a - ig_first);
+    const unsigned lane_off = (unsigned)(y_ok ? yl : y0) * (unsigned)W * 3u + 24u * kh;   // elements; the frame is bounded by bhr_create
+    auto load = [&](int ig, float (&a)[24]) {
+        const float *u = disk + (size_t)min(ig, W - 16) * 3;              // wave uniform; prefetch past the end: a re-read
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            const float4 f = *reinterpret_cast<const float4 *>(u + lane_off + 4 * v);
+            a[4 * v] = f.x; a[4 * v + 1] = f.y; a[4 * v + 2] = f.z; a[4 * v + 3] = f.w;
+        }
+    };
+    unsigned sel = 0x07060302u;
+    asm volatile("" : "+v"(sel));
+    auto chunk = [&](const float (&a)[24], const unsigned char *wq) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float xc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xc[j] = a[3 * j + c];
+            u32x4 ph_, pm_, pl_;
+            split8(xc, ph_, pm_, pl_, sel);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const unsigned char *q = wq + (3 * c) * part - 64 * t;
+                const u32x4 wh = *reinterpret_cast<const u32x4 *>(q);
+                const u32x4 wm = *reinterpret_cast<const u32x4 *>(q + part);
+                const u32x4 wlo = *reinterpret_cast<const u32x4 *>(q + 2 * part);
+                BHR_SPLIT_MFMA6(acc[c][t], ph_, pm_, pl_, wh, wm, wlo, true);
+            }
+        }
+    };
+    float a0[24], a1[24];                                     // two chunk buffers, alternating: see the V pass
+    load(ig_a, a0);
+    for (int ig = ig_a; ig <= ig_b;) {
+        load(ig + 16, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        chunk(a0, wl);
+        ig += 16; wl += 32;
+        if (ig > ig_b) break;
+        load(ig + 16, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        chunk(a1, wl);
+        ig += 16; wl += 32;
+    }
+    const size_t plane = (size_t)(rows + 2 * R) * W;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int x = x0 + 32 * t + n;
+        if (x >= W) continue;
+        const float s0w = wsum_h[x], s1w = wsum_h[W + x], s2w = wsum_h[2 * W + x];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int y = y0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (y >= row_end) continue;
+            const size_t o = (size_t)(y + R) * W + x;
+            hblur[o] = acc[0][t][r] / s0w;
+            hblur[plane + o] = acc[1][t][r] / s1w;
+            hblur[2 * plane + o] = acc[2][t][r] / s2w;
+        }
+    }
+}
+
 // V-pass geometry of this context: columns per block, row groups per thread (rows per block = 256 / cols x 4 x groups).
 // BHR_BLOOM_V="<cols>x<groups>" overrides ("32x0": the round-2 kernel with its own table below); BHR_BLOOM_H=<NG>.
 struct VGeom { int cols, groups, v2; };
 // Round-2 table of the 32-column kernel (v2 = 0): G = 1 (32 rows) up to fhd, 4 at 4k, 8 (256 rows) at 8k.
-VGeom v_geometry(int R, int rows) {
+VGeom v_geometry(int R, int rows, bool split) {
     // default: the matrix-core kernel, one 32-row tile per wave -- 1.03 / 0.190 / 0.041 ms at 8k / 4k / fhd against 1.78 /
     // 0.247 / 0.040 of the round-2 kernel and 1.21 / 0.193 / 0.041 of the 16-column VALU kernel (tools/exp_bloom.py)
     VGeom g{128, 1, 2};
+    if (split) g = VGeom{128, R >= 64 ? 2 : 1, 3};     // bf16 x 3: v2 = 3, groups = stacked tiles per wave
+    if (const char *e = getenv("BHR_BLOOM_V")) {
+        if (e[0] == 'b') {                         // "bf16x1" / "bf16x2"
+            const int t = atoi(e + 5);
+            return VGeom{128, t == 1 ? 1 : 2, 3};
+        }
+        if (split) return g;                       // the f32 variants below are the strict path's
+    }
     if (const char *e = getenv("BHR_BLOOM_V")) {
         if (e[0] != 'm') { g = VGeom{32, 1, 0}; if (R >= 64) g.groups = (R >= 128 && rows > 128) ? 8 : 4; }
     }
@@ -626,7 +949,7 @@ VGeom v_geometry(int R, int rows) {
     }
     return g;
 }
-int v_rows_per_block(const VGeom &g) { return g.v2 == 2 ? 32 * g.groups : 256 / g.cols * 4 * g.groups; }
+int v_rows_per_block(const VGeom &g) { return g.v2 >= 2 ? 32 * g.groups : 256 / g.cols * 4 * g.groups; }
 int v_stride(int R, const VGeom &g) {   // LDS column stride: >= tile rows, multiple of 4 with an odd quotient (bank spread)
     const int R4 = (R + 3) & ~3;
     int s = v_rows_per_block(g) + 2 * R4 + 4;
@@ -637,17 +960,24 @@ bool weights_in_lds() {
     if (const char *e = getenv("BHR_BLOOM_W")) return e[0] == 'l';
     return true;
 }
-int h_groups() {
+int h_groups(int R, bool split) {
     if (const char *e = getenv("BHR_BLOOM_H")) {
+        if (e[0] == 'b') return 200 + (atoi(e + 5) == 1 ? 1 : 2);                                                // "bf16x<T>"
+        if (split) return 200 + (R >= 64 ? 2 : 1);
         if (e[0] == 'm') { const int t = atoi(e + 4); return 100 + ((t == 1 || t == 2 || t == 4) ? t : 2); }   // "mfma<T>"
         int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) return v;
     }
     // measured at 8k / 4k / fhd (tools/exp_bloom.py, profiles/r03_bloom_variants.md): two groups per thread with the
     // weights as VGPR operands 0.87 / 0.127 / 0.026 ms; the round-2 kernel 0.97 / 0.146 / 0.030; the MFMA form 0.87 / 0.149 / 0.048
+    if (split) return 200 + (R >= 64 ? 2 : 1);
     return 2;
 }
 
 // kernels that need more than 48 KB of dynamic LDS are told so once
+// the bf16 kernels walk chunks of 16 that must lie whole inside or whole outside the image
+bool split_geometry_ok(const bhr_ctx *ctx) { return (ctx->cfg.width & 15) == 0 && (ctx->cfg.height & 15) == 0; }
+bool use_split(const bhr_ctx *ctx) { return ctx->bloom_split != 0 && split_geometry_ok(ctx); }
+
 int32_t allow_lds(const void *fn, size_t bytes) {
     static const void *done[64];
     static size_t done_bytes[64];
@@ -676,6 +1006,12 @@ int32_t bhr_bloom_prepare(bhr_ctx *ctx) {
     }
     hipLaunchKernelGGL(bloom_wsum_kernel, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wtab, ctx->d_wsum_h, R, W);
     hipLaunchKernelGGL(bloom_wsum_kernel, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wtab, ctx->d_wsum_v, R, H);
+    if (!ctx->d_wsplit) {
+        const size_t bytes = (size_t)72 * wsplit_cs(R);
+        BHR_HIP(hipMalloc(&ctx->d_wsplit, bytes));
+        BHR_HIP(hipMemsetAsync(ctx->d_wsplit, 0, bytes, ctx->stream));
+    }
+    hipLaunchKernelGGL(bloom_wsplit_kernel, dim3((3 * wsplit_nw(R) + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_wtab, ctx->d_wsplit, R);
     BHR_HIP(hipGetLastError());
     ctx->bloom_ready = 1;
     return BHR_OK;
@@ -689,7 +1025,19 @@ int32_t bhr_launch_bloom_h_rows(bhr_ctx *ctx, int32_t r0, int32_t r1) {
     if (r0 < 0 || r1 > ctx->rows || r0 > r1) return bhr_fail(BHR_ERR_INVALID, "bloom H: rows [%d,%d) of %d", r0, r1, ctx->rows);
     if (r0 == r1) return BHR_OK;
     const int R4 = (R + 3) & ~3;
-    const int ng = h_groups();
+    const int ng = h_groups(R, use_split(ctx));
+    if (ng >= 200) {
+        if (!split_geometry_ok(ctx)) return bhr_fail(BHR_ERR_INVALID, "bloom H: the bf16 kernels need width and height to be multiples of 16 (%d x %d)", W, ctx->cfg.height);
+        const int T = ng - 200;
+        dim3 mgrid((W + 32 * T - 1) / (32 * T), (r1 - r0 + 127) / 128), mblock(256);
+        const size_t mlds = (size_t)72 * wsplit_cs(R);
+#define BHR_HB_ARGS mgrid, mblock, mlds, ctx->stream, ctx->d_disk, ctx->d_hblur, ctx->d_wsplit, ctx->d_wsum_h, W, ctx->rows, R, r0, r1
+        if (T == 1) { BHR_TRY(allow_lds((const void *)bloom_h_bf16_kernel<1>, mlds)); hipLaunchKernelGGL(bloom_h_bf16_kernel<1>, BHR_HB_ARGS); }
+        else { BHR_TRY(allow_lds((const void *)bloom_h_bf16_kernel<2>, mlds)); hipLaunchKernelGGL(bloom_h_bf16_kernel<2>, BHR_HB_ARGS); }
+#undef BHR_HB_ARGS
+        BHR_HIP(hipGetLastError());
+        return BHR_OK;
+    }
     if (ng >= 100) {
         const int T = ng - 100;
         dim3 mgrid((W + 32 * T - 1) / (32 * T), (r1 - r0 + 127) / 128), mblock(256);
@@ -720,7 +1068,7 @@ int32_t bhr_launch_bloom_h_rows(bhr_ctx *ctx, int32_t r0, int32_t r1) {
 
 int32_t bhr_launch_bloom_h(bhr_ctx *ctx) { return bhr_launch_bloom_h_rows(ctx, 0, ctx->rows); }
 
-int32_t bhr_bloom_v_tile_rows(bhr_ctx *ctx) { return v_rows_per_block(v_geometry(ctx->bloom_R, ctx->rows)); }
+int32_t bhr_bloom_v_tile_rows(bhr_ctx *ctx) { return v_rows_per_block(v_geometry(ctx->bloom_R, ctx->rows, use_split(ctx))); }
 
 // V pass + combine over the local rows [r0, r1); u8_out != nullptr: also the quantised final rows ((rows, W, 3) u8 base)
 int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, int32_t r1, uint8_t *u8_out) {
@@ -729,7 +1077,20 @@ int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, in
     if (rc) return rc;
     if (r0 < 0 || r1 > ctx->rows || r0 > r1) return bhr_fail(BHR_ERR_INVALID, "bloom V: rows [%d,%d) of %d", r0, r1, ctx->rows);
     if (r0 == r1) return BHR_OK;
-    const VGeom g = v_geometry(R, ctx->rows);
+    const VGeom g = v_geometry(R, ctx->rows, use_split(ctx));
+    if (g.v2 == 3) {
+        if (!split_geometry_ok(ctx)) return bhr_fail(BHR_ERR_INVALID, "bloom V: the bf16 kernels need width and height to be multiples of 16 (%d x %d)", W, H);
+        const int vb = 32 * g.groups;
+        dim3 mgrid((W + 127) / 128, (r1 - r0 + vb - 1) / vb), mblock(256);
+        const size_t mlds = with_bloom ? (size_t)72 * wsplit_cs(R) : 0;
+#define BHR_VB_ARGS mgrid, mblock, mlds, ctx->stream, ctx->d_hblur, ctx->d_bg, ctx->d_disk, ctx->d_blur, ctx->d_final, ctx->d_wsplit, \
+                    ctx->d_wsum_v, W, H, ctx->cfg.row0, ctx->rows, R, with_bloom, ctx->v_zero_cell, r0, r1, u8_out
+        if (g.groups == 1) { BHR_TRY(allow_lds((const void *)bloom_v_bf16_kernel<1>, mlds)); hipLaunchKernelGGL(bloom_v_bf16_kernel<1>, BHR_VB_ARGS); }
+        else { BHR_TRY(allow_lds((const void *)bloom_v_bf16_kernel<2>, mlds)); hipLaunchKernelGGL(bloom_v_bf16_kernel<2>, BHR_VB_ARGS); }
+#undef BHR_VB_ARGS
+        BHR_HIP(hipGetLastError());
+        return BHR_OK;
+    }
     if (g.v2 == 2) {
         const int vb = 32 * g.groups;
         dim3 mgrid((W + 127) / 128, (r1 - r0 + vb - 1) / vb), mblock(256);

@@ -444,7 +444,7 @@ int32_t bhr_tile_export(bhr_ctx *ctx, uint32_t gather_flags, bhr_tile_handles *o
     memset(out, 0, sizeof(*out));
     static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(out->hblur), "handle size");
     hipIpcMemHandle_t h;
-    BHR_HIP(hipIpcGetMemHandle(&h, ctx->d_hblur));
+    BHR_HIP(hipIpcGetMemHandle(&h, ctx->slots[ctx->active_slot].d_hblur_base));   // handles name allocations: the planes start BHR_HBLUR_PAD_ROWS rows in
     memcpy(out->hblur, &h, sizeof(h));
     out->row0 = ctx->cfg.row0;
     out->rows = ctx->rows;
@@ -492,8 +492,9 @@ int32_t bhr_tile_connect(bhr_ctx *ctx, int32_t rank, int32_t world, const bhr_ti
         return BHR_OK;
     };
     p->nb_hblur[0] = p->nb_hblur[1] = nullptr;
-    if (with_up) { BHR_TRY(open(all[rank - 1].hblur, (void **)&p->nb_hblur[0], 0)); p->nb_rows[0] = all[rank - 1].rows; }
-    if (with_down) { BHR_TRY(open(all[rank + 1].hblur, (void **)&p->nb_hblur[1], 1)); p->nb_rows[1] = all[rank + 1].rows; }
+    const size_t pad = (size_t)BHR_HBLUR_PAD_ROWS * ctx->cfg.width;     // the handle opens the allocation; the planes start `pad` floats in
+    if (with_up) { BHR_TRY(open(all[rank - 1].hblur, (void **)&p->nb_hblur[0], 0)); p->nb_hblur[0] += pad; p->nb_rows[0] = all[rank - 1].rows; }
+    if (with_down) { BHR_TRY(open(all[rank + 1].hblur, (void **)&p->nb_hblur[1], 1)); p->nb_hblur[1] += pad; p->nb_rows[1] = all[rank + 1].rows; }
     p->gather_f32 = ctx->d_gather;
     p->gather_u8 = ctx->d_gather_u8;
     if (rank != 0) {

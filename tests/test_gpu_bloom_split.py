@@ -1,0 +1,121 @@
+"""The post-pass on the bf16 matrix cores (csrc/bloom.hip: f32 operands cut into three bf16 parts, six MFMA products per
+chunk of 16 taps), which the fast and hybrid arithmetic use from bloom radius 64 up (4k, 8k): against the exact f32
+kernels on the same layers, against the oracle's `_bloom_kernel` restatement (render.py:3022-3114), through properties at
+8k, and that row blocks give the same bits as one context (chunks are aligned to global multiples of 16)."""
+import numpy as np
+import pytest
+
+from bhr_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(step_size=0.1, r_max=10.0, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=0.0)
+CAM, FOV = [6.0, 0.0, 0.5], 90.0
+
+
+def _both_blooms(r, disk, bg):
+    """(blur, final) of the layers through the bf16 kernels and through the exact f32 kernels of one context"""
+    from bhr_amd import _lib
+    out = {}
+    for math in ("fast", "strict"):                        # the march of a frame picks the post-pass that follows it
+        r.render_async(CAM, FOV, math=math, skip_bloom=True)
+        r.write_layer(_lib.LAYER_DISK, disk)
+        r.write_layer(_lib.LAYER_BG, bg)
+        r.bloom_only()
+        out[math] = (r.read_layer(_lib.LAYER_BLUR), r.read_layer(_lib.LAYER_FINAL))
+    return out["fast"], out["strict"]
+
+
+def test_4k_split_bloom_against_exact_kernels_and_oracle(oracle, hip_lib):
+    from bhr_amd import HipRenderer, _lib
+    W, H = 3840, 2160
+    sky, tex = scenes.analytic_skybox(128, 256), scenes.noisy_disk(256, 1024)
+    r = HipRenderer(W, H, sky, tex, math="fast", frame_slots=1, **KW)
+    r.render_async(CAM, FOV)
+    disk, bg = r.read_layer(_lib.LAYER_DISK), r.read_layer(_lib.LAYER_BG)
+    assert disk.max() > 0.3
+    (blur_s, final_s), (blur_x, final_x) = _both_blooms(r, disk, bg)
+    r.close()
+    assert not np.array_equal(blur_s, blur_x)              # two different kernels did run
+    d = np.abs(blur_s - blur_x)
+    e = np.sqrt(np.mean(d.astype(np.float64) ** 2, axis=(0, 1)))
+    print(f"\n[bloom split] 4k blur layer, bf16 x 3 against exact f32: max {d.max():.3g}, per-channel RMSE {e}")
+    assert d.max() <= 3e-6 and (e <= 5e-7).all(), (d.max(), e)
+    assert np.abs(final_s - final_x).max() <= 3e-6
+    ora = oracle.OracleRenderer(W, H, sky, tex, **KW)
+    ref, _ = ora.bloom(disk.transpose(1, 0, 2))
+    ref = ref.transpose(1, 0, 2)
+    for name, got in (("bf16 x 3", blur_s), ("exact f32", blur_x)):
+        dd = np.abs(got - ref)
+        ee = np.sqrt(np.mean(dd.astype(np.float64) ** 2, axis=(0, 1)))
+        print(f"[bloom split] 4k blur layer, {name} against the oracle: max {dd.max():.3g}, per-channel RMSE {ee}")
+        assert dd.max() <= 5e-6 and (ee <= 1e-6).all(), (name, dd.max(), ee)
+
+
+def test_8k_split_bloom_properties(hip_lib):
+    """radius 153, two stacked tiles per wave: a constant layer is a fixed point (edges included), halving is exact,
+    the operator commutes with the left-right flip up to rounding, outputs are convex combinations of inputs"""
+    from bhr_amd import HipRenderer, _lib
+    W, H = 7680, 4320
+    r = HipRenderer(W, H, np.zeros((16, 32, 3), np.float32), np.zeros((32, 64, 4), np.float32), math="fast", frame_slots=1,
+                    **dict(KW, step_size=0.5))
+    r.render_async(CAM, FOV, skip_bloom=True)              # a fast frame: the bf16 post-pass is the context's
+    r.write_layer(_lib.LAYER_BG, np.zeros((H, W, 3), np.float32))
+
+    def bloom(x):
+        r.write_layer(_lib.LAYER_DISK, x)
+        r.bloom_only()
+        return r.read_layer(_lib.LAYER_BLUR)
+
+    const = np.empty((H, W, 3), np.float32)
+    const[...] = np.array([0.25, 0.5, 0.125], np.float32)
+    np.testing.assert_allclose(bloom(const), const, rtol=0, atol=3e-6)
+    rng = np.random.default_rng(8)
+    x = np.zeros((H, W, 3), np.float32)
+    ys, xs = rng.integers(0, H, 5000), rng.integers(0, W, 5000)
+    x[ys, xs] = rng.random((5000, 3), dtype=np.float32)
+    x[H // 3:H // 3 + 80, W // 5:W // 5 + 600] = 0.6
+    x[:3, :] = 0.9                                          # the image edges: skipped taps, per-pixel renormalisation
+    x[:, -2:] = 0.7
+    bx = bloom(x)
+    assert bx.max() > 0.05 and np.isfinite(bx).all()
+    np.testing.assert_array_equal(bloom(0.5 * x), 0.5 * bx)                             # exact: every part halves
+    np.testing.assert_allclose(bloom(np.ascontiguousarray(x[:, ::-1])), bx[:, ::-1], rtol=2e-5, atol=3e-6)
+    assert bx.max() <= x.max() + 3e-6 and bx.min() >= -1e-9
+    r.close()
+
+
+def test_split_bloom_row_blocks_equal_one_context_bit_for_bit(hip_lib):
+    """4k fast frame in 5 uneven row blocks (cuts not multiples of 16 or 32) == one context, every bit of the gathered
+    frame: an output's operands meet the same MFMA slots whatever the tiling"""
+    from bhr_amd import HipRenderer, multigpu
+    W, H = 3840, 2160
+    sky, tex = scenes.analytic_skybox(128, 256), scenes.noisy_disk(256, 1024)
+    full = HipRenderer(W, H, sky, tex, math="fast", frame_slots=1, **KW)
+    ref = full.render(CAM, FOV)
+    full.close()
+    cuts = [0, 401, 918, 1247, 1795, H]
+    tiles = [HipRenderer(W, H, sky, tex, rows=(cuts[k], cuts[k + 1]), math="fast", frame_slots=1, **KW) for k in range(5)]
+    for sched in ("serial", "pipelined"):
+        multigpu.group_render(tiles, CAM, FOV, gather="peer", schedule=sched)
+        np.testing.assert_array_equal(multigpu.read_gathered(tiles), ref)
+    for t in tiles:
+        t.close()
+
+
+def test_split_needs_multiples_of_16_and_falls_back(hip_lib):
+    """fhd (height 1080 = 16 x 67.5, radius 38): the fast arithmetic keeps the f32 post-pass there"""
+    from bhr_amd import HipRenderer, _lib
+    s = scenes.SCENES["default"]
+    sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
+    a = HipRenderer(s["width"], s["height"], sky, tex, math="fast", **s["kw"])
+    b = HipRenderer(s["width"], s["height"], sky, tex, math="strict", **s["kw"])
+    a.render_async([6, 0, 0.5], 90)
+    disk, bg = a.read_layer(_lib.LAYER_DISK), a.read_layer(_lib.LAYER_BG)
+    b.render_async([6, 0, 0.5], 90, skip_bloom=True)
+    b.write_layer(_lib.LAYER_DISK, disk)
+    b.write_layer(_lib.LAYER_BG, bg)
+    b.bloom_only()
+    np.testing.assert_array_equal(a.read_layer(_lib.LAYER_BLUR), b.read_layer(_lib.LAYER_BLUR))
+    a.close()
+    b.close()

@@ -9,8 +9,8 @@ from bhr_amd import HipRenderer, _lib, scenes
 
 SIZES = {"8k": (7680, 4320, None, 0.05), "4k": (3840, 2160, None, 0.1),
          "fhd": (1920, 1080, None, 0.1)}
-H_VARIANTS = ["0", "2l", "mfma1", "mfma2", "mfma4"]          # "<NG>l": weights in LDS (VGPR operands)
-V_VARIANTS = ["32x0", "16x2", "16x4", "16x4l", "mfma1", "mfma2", "mfma4"]
+H_VARIANTS = ["0", "2l", "mfma1", "mfma2", "mfma4", "bf16x1", "bf16x2"]          # "<NG>l": weights in LDS (VGPR operands)
+V_VARIANTS = ["32x0", "16x2", "16x4", "16x4l", "mfma1", "mfma2", "mfma4", "bf16x1", "bf16x2"]
 
 
 def time_pass(r, only, n):
@@ -30,6 +30,7 @@ def time_pass(r, only, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="8k,4k,fhd")
+    ap.add_argument("--only", default=None, help="comma list of variants to run (both passes)")
     ap.add_argument("--quick", default=None, help="H,V variant pair only (profiling), e.g. 0,32x0")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bloom_variants.json"))
     a = ap.parse_args()
@@ -44,27 +45,34 @@ def main():
         n = 20 if W > 4000 else 50
         if a.quick:
             hv, vv = a.quick.split(",")
-            os.environ["BHR_BLOOM_W"] = "lds" if (hv.endswith("l") and not hv.startswith("m")) or (vv.endswith("l") and not vv.startswith("m")) else "sgpr"
-            os.environ["BHR_BLOOM_H"], os.environ["BHR_BLOOM_V"] = (hv if hv.startswith("m") else hv.rstrip("l")), (vv if vv.startswith("m") else vv.rstrip("l"))
+            os.environ["BHR_BLOOM_W"] = "lds" if (hv.endswith("l") and not hv.startswith(("m", "b"))) or (vv.endswith("l") and not vv.startswith(("m", "b"))) else "sgpr"
+            os.environ["BHR_BLOOM_H"], os.environ["BHR_BLOOM_V"] = (hv if hv.startswith(("m", "b")) else hv.rstrip("l")), (vv if vv.startswith(("m", "b")) else vv.rstrip("l"))
             print(name, a.quick, "H", round(time_pass(r, "h", n), 4), "V", round(time_pass(r, "v", n), 4), flush=True)
             r.close()
             continue
         r.bloom_only()
         base_blur, base_final = r.read_layer(_lib.LAYER_BLUR), r.read_layer(_lib.LAYER_FINAL)
         out = {"H": {}, "V": {}}
-        for hv in H_VARIANTS:
-            os.environ["BHR_BLOOM_H"] = hv if hv.startswith("m") else hv.rstrip("l")
-            os.environ["BHR_BLOOM_W"] = "lds" if (hv.endswith("l") and not hv.startswith("m")) else "sgpr"
+        hvs = [v for v in H_VARIANTS if not a.only or v in a.only.split(",")]
+        vvs = [v for v in V_VARIANTS if not a.only or v in a.only.split(",")]
+        for hv in hvs:
+            os.environ["BHR_BLOOM_H"] = hv if hv.startswith(("m", "b")) else hv.rstrip("l")
+            os.environ["BHR_BLOOM_W"] = "lds" if (hv.endswith("l") and not hv.startswith(("m", "b"))) else "sgpr"
             os.environ["BHR_BLOOM_V"] = "32x0"
-            r.bloom_only()
+            try:
+                r.bloom_only()
+            except ValueError as e:
+                out["H"][hv] = {"error": str(e)[:200]}
+                print(name, "H", hv, out["H"][hv], flush=True)
+                continue
             blur = r.read_layer(_lib.LAYER_BLUR)
             same = bool(np.array_equal(blur, base_blur))
             out["H"][hv] = {"ms": time_pass(r, "h", n), "bit_identical": same, "max_diff_blur": float(np.abs(blur - base_blur).max())}
             print(name, "H", hv, out["H"][hv], flush=True)
         os.environ["BHR_BLOOM_H"] = "0"
-        for vv in V_VARIANTS:
-            os.environ["BHR_BLOOM_V"] = vv if vv.startswith("m") else vv.rstrip("l")
-            os.environ["BHR_BLOOM_W"] = "lds" if (vv.endswith("l") and not vv.startswith("m")) else "sgpr"
+        for vv in vvs:
+            os.environ["BHR_BLOOM_V"] = vv if vv.startswith(("m", "b")) else vv.rstrip("l")
+            os.environ["BHR_BLOOM_W"] = "lds" if (vv.endswith("l") and not vv.startswith(("m", "b"))) else "sgpr"
             try:
                 r.bloom_only()
                 blur, fin = r.read_layer(_lib.LAYER_BLUR), r.read_layer(_lib.LAYER_FINAL)
