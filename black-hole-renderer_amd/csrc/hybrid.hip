@@ -101,8 +101,15 @@ void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, s
                 pd += cp[k] * d[k];
             }
             pd /= sqrt(dn);
-            const double b2 = r0sq - pd * pd;
-            bgrid[(size_t)gy * gx_n + gx] = (float)sqrt(b2 > 0 ? b2 : 0);
+            // The orbit is fixed by the first integral of the path equation the reference integrates (u'' + u = 3/2 u^2,
+            // u = 1 / r; render.py:2928-2934 is its Cartesian form):  u'^2 + u^2 - u^3 = 1 / b_l^2 - 1 / r0^3  with the LOCAL
+            // moment b_l = |pos x dir| -- not by b_l itself.  The ray whirls at the photon sphere when that integral is
+            // 4 / 27 = 1 / b_c^2; expressed as a length, b = (1 / b_l^2 - 1 / r0^3)^(-1/2), which is b_l for a far camera, 1.6 %
+            // more at the default pov (6 r_s) and 17 % more at 2.6 r_s (found by the fuzzed views of tests/test_gpu_fuzz.py:
+            // a band on b_l missed every near-critical ray of cameras inside 3 r_s).
+            const double bl2 = r0sq - pd * pd;
+            const double inv = (bl2 > 1e-12 ? 1.0 / bl2 : 1e12) - 1.0 / (r0sq * sqrt(r0sq));
+            bgrid[(size_t)gy * gx_n + gx] = (float)(inv > 1e-6 ? 1.0 / sqrt(inv) : 1e3);
             outgoing[(size_t)gy * gx_n + gx] = pd > 0;
         }
     }
@@ -115,8 +122,8 @@ void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, s
             float bmin = c[0], bmax = c[0];
             for (int k = 1; k < 4; ++k) { bmin = c[k] < bmin ? c[k] : bmin; bmax = c[k] > bmax ? c[k] : bmax; }
             if (far_cam && outgoing[g] && outgoing[g + 1] && outgoing[g + gx_n] && outgoing[g + gx_n + 1]) continue;
-            // b is the distance from the hole's image in a convex sense: its maximum over the tile is at a corner, its
-            // minimum may lie on an edge -- pad by the tile's own span
+            // b grows with the distance from the hole's image in a convex sense (the field of view stays under 180 degrees): its
+            // maximum over the tile is at a corner, its minimum may lie on an edge -- pad by the tile's own span
             const double pad = (double)(bmax - bmin) + 1e-3;
             if (bmax + pad >= B_CRIT - lo && bmin - pad <= B_CRIT + hi) strict[(size_t)ty * tiles_x + tx] = 1;
         }
@@ -162,8 +169,8 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
         h->valid = 0;
         h->n_strict = 0;
         // band around b_c, in r_s: measured on the fixtures and the fhd / 4k / e2e frames (tools/hybrid_sweep.py)
-        h->lo = 0.12;
-        h->hi = 0.30;
+        h->lo = 0.085;       // in the orbit's own b (classify): the band certified in round 3 on |pos x dir| at the 6 r_s pov,
+        h->hi = 0.36;        // [2.478, 2.898], is [b_c - 0.084, b_c + 0.357] there
         if (const char *e = getenv("BHR_HYBRID_BAND")) {
             double a = 0, b = 0;
             if (sscanf(e, "%lf,%lf", &a, &b) == 2 && a >= 0 && b >= 0) { h->lo = a; h->hi = b; }
