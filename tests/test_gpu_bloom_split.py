@@ -119,3 +119,42 @@ def test_split_needs_multiples_of_16_and_falls_back(hip_lib):
     np.testing.assert_array_equal(a.read_layer(_lib.LAYER_BLUR), b.read_layer(_lib.LAYER_BLUR))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_row_blocks_and_sizes_split_bloom(seed, hip_lib, monkeypatch):
+    """Small frames with the bf16 post-pass forced on (radius 6 ... 25, one and two tiles per wave), cut into 2-6 random
+    row blocks, some thinner than the radius (multi-hop halo): the gathered frame of both schedules == one context bit for
+    bit, and the one-context frame sits within 3e-6 of the exact f32 kernels."""
+    from bhr_amd import HipRenderer, multigpu
+    rng = np.random.default_rng(100 + seed)
+    W, H = [(640, 400), (320, 208), (960, 544), (1280, 720)][seed % 4]
+    monkeypatch.setenv("BHR_BLOOM_SPLIT", "1")
+    if seed >= 4:
+        monkeypatch.setenv("BHR_BLOOM_H", "bf16x2")
+        monkeypatch.setenv("BHR_BLOOM_V", "bf16x2")
+    sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
+    kw = dict(KW, disk_tilt=float(rng.uniform(-30, 30)))
+    cam = [float(rng.uniform(4, 9)), float(rng.uniform(-2, 2)), float(rng.uniform(-1.5, 1.5))]
+    full = HipRenderer(W, H, sky, tex, math="fast", frame_slots=1, **kw)
+    ref = full.render(cam, FOV)
+    monkeypatch.setenv("BHR_BLOOM_SPLIT", "0")
+    monkeypatch.delenv("BHR_BLOOM_H", raising=False)
+    monkeypatch.delenv("BHR_BLOOM_V", raising=False)
+    exact = full.render(cam, FOV)
+    full.close()
+    assert not np.array_equal(ref, exact) and np.abs(ref - exact).max() <= 3e-6
+    monkeypatch.setenv("BHR_BLOOM_SPLIT", "1")
+    if seed >= 4:
+        monkeypatch.setenv("BHR_BLOOM_H", "bf16x2")
+        monkeypatch.setenv("BHR_BLOOM_V", "bf16x2")
+    n = int(rng.integers(2, 7))
+    inner = np.sort(rng.choice(np.arange(3, H - 3), size=n - 1, replace=False))
+    inner = [int(c) for c in inner]
+    cuts = [0] + [c for k, c in enumerate(inner) if k == 0 or c - inner[k - 1] >= 3] + [H]
+    tiles = [HipRenderer(W, H, sky, tex, rows=(cuts[k], cuts[k + 1]), math="fast", frame_slots=1, **kw) for k in range(len(cuts) - 1)]
+    for sched in ("serial", "pipelined"):
+        multigpu.group_render(tiles, cam, FOV, gather="peer", schedule=sched)
+        np.testing.assert_array_equal(multigpu.read_gathered(tiles), ref, err_msg=f"{W}x{H} cuts {cuts} {sched}")
+    for t in tiles:
+        t.close()
