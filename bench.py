@@ -162,7 +162,7 @@ def tile_leg_per_rank(wl, rank, world, local_rank, dist, frames, math=None, warm
     halo rows and rank 0's frame buffer, shared-memory counters for the pacing): what `--strong` runs when a rank sees
     only its own GPU.  Every rank calls this; rank 0 gets the result, the others None."""
     from bhr_amd import distributed as D, multigpu, workloads
-    blocks = workloads.plan_blocks(wl, world, local_rank)
+    blocks = workloads.plan_blocks(wl, world, local_rank, math=math)
     tile, dims = workloads.make_tile(wl, blocks[rank], local_rank, math=math)
     shm = f"bhr_tiles_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
     link = multigpu.TileLink(tile, rank, world, lambda b: D.host_all_gather_bytes(b, dist), shm, gather="peer_u8")

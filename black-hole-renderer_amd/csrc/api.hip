@@ -797,7 +797,21 @@ int32_t bhr_get_row_costs(bhr_ctx *ctx, uint64_t *out, int32_t n) {
     if (!ctx->d_row_steps || !(ctx->last_flags & BHR_ROW_COSTS))
         return bhr_fail(BHR_ERR_STATE, "bhr_get_row_costs: the last bhr_render did not carry BHR_ROW_COSTS");
     BHR_TRY(use_device(ctx));
-    return download(ctx, out, ctx->d_row_steps, (size_t)bands * sizeof(uint64_t));
+    std::vector<uint64_t> both((size_t)2 * bands);
+    BHR_TRY(download(ctx, both.data(), ctx->d_row_steps, both.size() * sizeof(uint64_t)));
+    for (int32_t k = 0; k < bands; ++k) out[k] = both[(size_t)k] + both[(size_t)bands + k];
+    return BHR_OK;
+}
+
+int32_t bhr_get_row_costs_split(bhr_ctx *ctx, uint64_t *fast_out, uint64_t *strict_out, int32_t n) {
+    if (!ctx || !fast_out || !strict_out) return bhr_fail(BHR_ERR_INVALID, "bhr_get_row_costs_split: bad argument");
+    const int32_t bands = (ctx->rows + 7) / 8;
+    if (n != bands) return bhr_fail(BHR_ERR_INVALID, "bhr_get_row_costs_split: the context has %d 8-row bands, caller asked for %d", bands, n);
+    if (!ctx->d_row_steps || !(ctx->last_flags & BHR_ROW_COSTS))
+        return bhr_fail(BHR_ERR_STATE, "bhr_get_row_costs_split: the last bhr_render did not carry BHR_ROW_COSTS");
+    BHR_TRY(use_device(ctx));
+    BHR_TRY(download(ctx, fast_out, ctx->d_row_steps, (size_t)bands * sizeof(uint64_t)));
+    return download(ctx, strict_out, ctx->d_row_steps + bands, (size_t)bands * sizeof(uint64_t));
 }
 
 int32_t bhr_timing_reset(bhr_ctx *ctx) {

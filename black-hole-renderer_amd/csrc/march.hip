@@ -1247,7 +1247,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         if (flags & BHR_FORCE_HYBRID) mode = BHR_MATH_HYBRID;
         // hybrid = two launches over complementary tile lists (hybrid.hip); schedules and disk sources that have no
         // list form run strict
-        if (mode == BHR_MATH_HYBRID && (ctx->disk_source != BHR_DISK_TEXTURE || (flags & (BHR_PERSISTENT | BHR_ROW_COSTS)))) mode = BHR_MATH_STRICT;
+        if (mode == BHR_MATH_HYBRID && (ctx->disk_source != BHR_DISK_TEXTURE || (flags & BHR_PERSISTENT))) mode = BHR_MATH_STRICT;
         // the frame's post-pass follows its march: exact f32 chains under strict, the bf16 x 3 matrix-core kernels (bloom.hip)
         // under fast and hybrid where they pay (radius >= 64: 4k and up); BHR_BLOOM_SPLIT=0 / 1 forces either for every arithmetic
         {
@@ -1337,10 +1337,12 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     const bool first_part = !part.active || part.first, last_part = !part.active || part.last;
     a.row_steps = nullptr;
     if (flags & BHR_ROW_COSTS) {
+        // two profiles side by side: [0, n) the steps taken by the fast arithmetic, [n, 2n) by the strict one (a hybrid frame
+        // fills both, from its two tile lists); cleared by the frame's first part, on the stream every other part follows
         const size_t n = (size_t)((ctx->rows + 7) / 8);
-        if (!ctx->d_row_steps) BHR_HIP(hipMalloc((void **)&ctx->d_row_steps, n * sizeof(unsigned long long)));
-        BHR_HIP(hipMemsetAsync(ctx->d_row_steps, 0, n * sizeof(unsigned long long), ctx->stream));
-        a.row_steps = ctx->d_row_steps;
+        if (!ctx->d_row_steps) BHR_HIP(hipMalloc((void **)&ctx->d_row_steps, 2 * n * sizeof(unsigned long long)));
+        if (first_part) BHR_HIP(hipMemsetAsync(ctx->d_row_steps, 0, 2 * n * sizeof(unsigned long long), ctx->stream));
+        a.row_steps = ctx->d_row_steps + (BHR_MARCH_STRICT ? n : 0);
     }
     a.wave_stamps = nullptr;
     // diagnostic (builds with -DBHR_WAVE_STAMPS_BUILD=1 only: the stamps cost the plain kernel three spilled registers):

@@ -55,17 +55,29 @@ def balanced_row_blocks(height: int, n: int, band_costs: Sequence[float], band_r
     return [(cuts[k], cuts[k + 1]) for k in range(n)]
 
 
-def probe_row_costs(width: int, height: int, cam_pos, fov: float, scale: int = 8, device_index: int = 0, **kw):
+STRICT_STEP_COST = 2.2      # cost of a ray-step of the strict kernel in units of the fast kernel's (207 / 98 VALU per wave-step)
+
+
+def probe_row_costs(width: int, height: int, cam_pos, fov: float, scale: int = None, device_index: int = 0, math=None, **kw):
     """(band_costs, band_rows) of a width x height frame from a frame ``scale`` times smaller: the number of
     steps a ray takes depends on the camera, the step size and the escape radius, not on the textures, so the
-    probe runs with placeholder textures (a fraction of a millisecond)."""
+    probe runs with placeholder textures (a fraction of a millisecond).  math="hybrid": the probe marches hybrid and
+    the steps its strict tiles took (the rows through the photon ring) count STRICT_STEP_COST times.  scale: 8, or 2 for
+    hybrid -- the strict set is chosen per 8x8 tile with a margin of one tile, so a coarse probe would see a thicker ring
+    than the full frame has (a 4k probe of an 8k frame takes 1.5 ms)."""
     from .renderer import HipRenderer
+    if scale is None:
+        scale = 2 if math == "hybrid" else 8
     keep = {k: kw[k] for k in ("step_size", "r_max", "r_disk_inner", "r_disk_outer", "disk_tilt") if k in kw}
     pw, ph = max(8, width // scale), max(8, height // scale)
     probe = HipRenderer(pw, ph, np.zeros((8, 16, 3), np.float32), np.zeros((32, 64, 4), np.float32),
-                        device_index=device_index, math="fast", **keep)
+                        device_index=device_index, math="hybrid" if math == "hybrid" else "fast", **keep)
     try:
-        costs = probe.row_costs(cam_pos, fov).astype(np.float64)
+        if math == "hybrid":
+            fast, strict = probe.row_costs(cam_pos, fov, split=True)
+            costs = fast.astype(np.float64) + STRICT_STEP_COST * strict.astype(np.float64)
+        else:
+            costs = probe.row_costs(cam_pos, fov).astype(np.float64)
     finally:
         probe.close()
     band_rows = 8 * height / ph                                   # probe band of 8 rows -> rows of the full image
@@ -224,7 +236,7 @@ def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devi
         raise ValueError(f"{gpus} row blocks need {gpus} device ordinals, got {devices}")
     blocks = row_blocks(height, gpus)
     if balance and gpus > 1 and height >= 64 * gpus:
-        per_row, band_rows = probe_row_costs(width, height, cam_pos, fov, device_index=devices[0], **kw)
+        per_row, band_rows = probe_row_costs(width, height, cam_pos, fov, device_index=devices[0], math=math, **kw)
         blocks = balanced_row_blocks(height, gpus, per_row, band_rows, fixed_cost_per_row=0.1 * float(per_row.mean()))
     tiles = []
     for k, rows in enumerate(blocks):

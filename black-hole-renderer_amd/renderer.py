@@ -409,13 +409,20 @@ class HipRenderer:
         _lib.check(self._lib.bhr_lens_flare_sums(self._ctx, out))
         return np.array(out[:], dtype=np.float64)
 
-    def row_costs(self, cam_pos, fov: float) -> np.ndarray:
-        """Ray-steps per band of 8 rows for this view (one march with BHR_ROW_COSTS, no bloom)."""
+    def row_costs(self, cam_pos, fov: float, split: bool = False):
+        """Ray-steps per band of 8 rows for this view (one march with BHR_ROW_COSTS, no bloom).  split=True: the pair
+        (steps taken by the fast arithmetic, steps taken by the strict arithmetic) -- a hybrid frame has both."""
         cam = self.camera_uniforms(cam_pos, fov, 0)
         flags = self._flags(True, True) | _lib.ROW_COSTS
         _lib.check(self._lib.bhr_render(self._ctx, C.byref(cam), flags))
-        out = np.zeros((self.rows + 7) // 8, dtype=np.uint64)
-        _lib.check(self._lib.bhr_get_row_costs(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)), len(out)))
+        n = (self.rows + 7) // 8
+        u64p = C.POINTER(C.c_uint64)
+        if split:
+            fast, strict = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+            _lib.check(self._lib.bhr_get_row_costs_split(self._ctx, fast.ctypes.data_as(u64p), strict.ctypes.data_as(u64p), n))
+            return fast, strict
+        out = np.zeros(n, dtype=np.uint64)
+        _lib.check(self._lib.bhr_get_row_costs(self._ctx, out.ctypes.data_as(u64p), n))
         return out
 
     def read_final_u8(self) -> np.ndarray:

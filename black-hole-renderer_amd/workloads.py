@@ -30,7 +30,7 @@ def make_scene(wl: dict, device_index: int = 0, n_stars: int = 6000, math=None, 
     return r, sky, tex, note
 
 
-def plan_blocks(wl: dict, n: int, device_index: int = 0, balance: bool = True):
+def plan_blocks(wl: dict, n: int, device_index: int = 0, balance: bool = True, math=None):
     """The n row blocks of workload ``wl``: cut by the cost profile of a probe frame rendered on ``device_index``
     (multigpu.balanced_row_blocks) -- deterministic, so every rank of a one-process-per-tile run computes the same cut."""
     from . import multigpu
@@ -38,7 +38,7 @@ def plan_blocks(wl: dict, n: int, device_index: int = 0, balance: bool = True):
     kw = dict(step_size=wl["step_size"], r_max=10.0, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=wl["disk_tilt"])
     blocks = multigpu.row_blocks(H, n)
     if balance and n > 1 and H >= 64 * n:
-        per_row, band_rows = multigpu.probe_row_costs(W, H, wl["cam_pos"], wl["fov"], device_index=device_index, **kw)
+        per_row, band_rows = multigpu.probe_row_costs(W, H, wl["cam_pos"], wl["fov"], device_index=device_index, math=math, **kw)
         blocks = multigpu.balanced_row_blocks(H, n, per_row, band_rows, fixed_cost_per_row=0.1 * float(per_row.mean()))
     return blocks
 
@@ -64,7 +64,7 @@ def make_tiles(wl: dict, devices, n_stars: int = 6000, math=None, balance: bool 
     ``devices[k]``, every device with its own copy of the deterministic scene, rows cut by the cost profile of a
     probe frame (multigpu.balanced_row_blocks).  Returns (tiles, blocks, note); render with multigpu.group_render."""
     n = len(devices)
-    blocks = plan_blocks(wl, n, devices[0], balance)
+    blocks = plan_blocks(wl, n, devices[0], balance, math=math)
     tiles, dims = [], None
     for dev, rows in zip(devices, blocks):
         r, dims = make_tile(wl, rows, dev, n_stars=n_stars, math=math)

@@ -80,7 +80,7 @@ typedef struct {
  * have b within a band around b_c are marched by the STRICT kernel -- bit-identical paths, as math_mode 1 -- and all
  * other tiles by the FAST kernel, as two launches over complementary tile lists.  Pixels stay within the 1e-4 bar of
  * the reference's statements on every fixture; ray-step totals within 2e-4.  Schedules / disk sources
- * without a tile-list form (BHR_PERSISTENT, BHR_ROW_COSTS, Disk V2) run STRICT.  With anti_alias = 1 the mip level is a
+ * without a tile-list form (BHR_PERSISTENT, Disk V2) run STRICT.  With anti_alias = 1 the mip level is a
  * truncated function of the ray differentials, which rounding noise flips on level boundaries: the fast tiles' kernel
  * then carries guards -- a lane within a guard band of a level boundary (or of another switch of the algorithm: a disk
  * crossing in the terminating step, a step that ends on the disk plane, the disk's edges) hands its pixel to a third
@@ -265,6 +265,10 @@ BHR_API int32_t bhr_timing_dump(bhr_ctx *ctx, float *out, int32_t n);
  * The step count of a ray depends on the camera, the step size and the escape radius only -- not on the
  * textures -- so a small probe frame gives the cost profile of a large one (multigpu.balanced_row_blocks). */
 BHR_API int32_t bhr_get_row_costs(bhr_ctx *ctx, uint64_t *out, int32_t n);
+/* The same profile split by the arithmetic that took the steps: a math_mode 2 (hybrid) frame marches its tiles near the
+ * photon ring with the strict kernel, ~2.2x the cost per step of the fast one -- row blocks of hybrid frames are balanced
+ * on fast + 2.2 strict (multigpu.probe_row_costs).  A strict frame has everything in strict_out, a fast one in fast_out. */
+BHR_API int32_t bhr_get_row_costs_split(bhr_ctx *ctx, uint64_t *fast_out, uint64_t *strict_out, int32_t n);
 
 /* ---- multi-GPU row-block tiling (one process driving N devices) -----------
  * ctxs[k] renders rows [row0_k,row1_k) of the same image; blocks must be

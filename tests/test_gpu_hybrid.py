@@ -201,3 +201,35 @@ def test_hybrid_guards_catch_the_algorithm_s_own_switches(hip_lib, capsys, monke
         print(f"\n[hybrid guards] 4k tilt 25, AA off, disk layer vs strict (max, pixels > 0.05, per-channel RMSE): guards on {out['default']}, off {out['0']}")
     assert out["default"][0] <= 0.05 and out["default"][1] == 0, out
     assert out["default"][2] <= 5e-5 and out["0"][2] <= 1e-3, out
+
+
+def test_row_costs_split_by_arithmetic_and_hybrid_balanced_blocks(hip_lib):
+    """BHR_ROW_COSTS under hybrid: the two tile lists fill two profiles (fast steps, strict steps) whose sum is the frame's
+    ray-step total; the strict profile is confined to the rows through the photon ring; row blocks balanced on
+    fast + STRICT_STEP_COST x strict move rows away from the blocks that hold the ring."""
+    from bhr_amd import HipRenderer, multigpu, scenes
+    W, H = 960, 544
+    sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
+    kw = dict(step_size=0.1, r_max=10.0, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=0.0)
+    cam, fov = [6.0, 0.0, 0.5], 90.0
+    r = HipRenderer(W, H, sky, tex, math="hybrid", **kw)
+    fast, strict = r.row_costs(cam, fov, split=True)
+    total = r.row_costs(cam, fov)
+    np.testing.assert_array_equal(fast + strict, total)
+    assert strict.sum() > 0 and fast.sum() > 0
+    rows_with_strict = np.nonzero(strict)[0]
+    assert rows_with_strict.min() > 5 and rows_with_strict.max() < len(strict) - 6      # the ring sits in the middle bands
+    s = HipRenderer(W, H, sky, tex, math="strict", **kw)
+    f0, s0 = s.row_costs(cam, fov, split=True)
+    assert f0.sum() == 0 and s0.sum() > 0
+    # the same rays whichever arithmetic: step totals of the hybrid frame within 2e-4 of the strict frame's
+    assert abs(int(total.sum()) - int(s0.sum())) <= 2e-4 * s0.sum() + 64 * 8
+    r.close()
+    s.close()
+    per_f, _ = multigpu.probe_row_costs(3840, 2160, cam, fov, math=None, **kw)
+    per_h, _ = multigpu.probe_row_costs(3840, 2160, cam, fov, math="hybrid", **kw)
+    bf = multigpu.balanced_row_blocks(2160, 8, per_f, 1, fixed_cost_per_row=0.1 * float(per_f.mean()))
+    bh = multigpu.balanced_row_blocks(2160, 8, per_h, 1, fixed_cost_per_row=0.1 * float(per_h.mean()))
+    mid_f = sum(b[1] - b[0] for b in bf[2:6])
+    mid_h = sum(b[1] - b[0] for b in bh[2:6])
+    assert mid_h < mid_f, (bf, bh)                     # the four middle blocks (the ring's) get fewer rows under hybrid costs
