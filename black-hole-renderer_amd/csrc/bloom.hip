@@ -22,6 +22,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "bhr_internal.h"
 
 namespace {
@@ -978,15 +980,23 @@ int h_groups(int R, bool split) {
 bool split_geometry_ok(const bhr_ctx *ctx) { return (ctx->cfg.width & 15) == 0 && (ctx->cfg.height & 15) == 0; }
 bool use_split(const bhr_ctx *ctx) { return ctx->bloom_split != 0 && split_geometry_ok(ctx); }
 
+// (a function attribute belongs to the device it was set on: the note is kept per (device, kernel) -- row-block tiles on the
+// eight devices of a node launch the same kernels from one process)
 int32_t allow_lds(const void *fn, size_t bytes) {
-    static const void *done[64];
-    static size_t done_bytes[64];
+    constexpr int CAP = 256;
+    static const void *done[CAP];
+    static size_t done_bytes[CAP];
+    static int done_dev[CAP];
     static int n_done = 0;
+    static std::mutex mu;
     if (bytes <= 48 * 1024) return BHR_OK;
+    int dev = 0;
+    BHR_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);           // group renders submit from one host thread per tile
     for (int k = 0; k < n_done; ++k)
-        if (done[k] == fn && done_bytes[k] >= bytes) return BHR_OK;
+        if (done[k] == fn && done_dev[k] == dev && done_bytes[k] >= bytes) return BHR_OK;
     BHR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    if (n_done < 64) { done[n_done] = fn; done_bytes[n_done++] = bytes; }
+    if (n_done < CAP) { done[n_done] = fn; done_dev[n_done] = dev; done_bytes[n_done++] = bytes; }
     return BHR_OK;
 }
 
