@@ -1,5 +1,5 @@
 """Video driver throughput at fhd (configs[4]): frames/s end to end with the frame sink, and the
-time of each stage.  Usage: python tools/exp_video.py [n_frames] [png_level, -1 = device encoder] [workers]"""
+time of each stage.  Usage: python tools/exp_video.py [n_frames] [png_level, -1 = device encoder] [workers] [math = hybrid]"""
 import os, sys, time, shutil, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,9 +7,10 @@ from bhr_amd import drivers
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 workers = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+math = sys.argv[4] if len(sys.argv) > 4 else "hybrid"
 print("cpus", len(os.sched_getaffinity(0)), flush=True)
 tmp = tempfile.mkdtemp(prefix="bhr_video_")
-r, _, _, _ = drivers.make_renderer(1920, 1080, [6, 0, 0.5], 90, n_stars=6000)
+r, _, _, _ = drivers.make_renderer(1920, 1080, [6, 0, 0.5], 90, n_stars=6000, math=math)
 t0 = time.perf_counter()
 drivers.render_video(r, 1920, 1080, n_frames=n, fps=30, output_path=os.path.join(tmp, "v.mp4"), fov=90,
                      static_cam_pos=[6, 0, 0.5], orbit=True, assemble=False, png_level=level, sink_workers=workers)
