@@ -160,21 +160,41 @@ def _frames_dir(output_path: str) -> str:
 
 
 def assemble_video(temp_dir: str, n_frames: int, fps: int, output_path: str) -> bool:
-    """PNG frames -> libx264 MP4 through imageio's pyav plugin (render.py:4497-4503).  Returns False
-    (frames are kept) when imageio / av are not installed."""
+    """PNG frames -> MP4 (render.py:4497-4503: libx264 through imageio's pyav plugin).  In order of preference: imageio +
+    pyav as the reference; an ``ffmpeg`` binary on PATH (same codec, same pixel format); failing both, the frames
+    themselves muxed into an MP4 as PNG-coded samples (mp4.write_png_mp4: lossless, plays in ffmpeg / mpv / VLC, and is one
+    ffmpeg call away from the H.264 file).  Returns False only when a frame is missing."""
+    frames = [os.path.join(temp_dir, f"frame_{frame:04d}.png") for frame in range(n_frames)]
+    missing = [p for p in frames if not os.path.isfile(p)]
+    if missing:
+        print(f"{len(missing)} of {n_frames} frames are missing (first: {missing[0]}): no video assembled")
+        return False
     try:
         import imageio.v3 as iio
         import av  # noqa: F401
     except ImportError:
-        print(f"imageio/pyav not available: frames kept in {temp_dir}; encode with\n"
-              f"  ffmpeg -framerate {fps} -i {temp_dir}/frame_%04d.png -c:v libx264 -crf 18 -pix_fmt yuv420p {output_path}")
-        return False
-    writer = iio.imopen(output_path, "w", plugin="pyav")
-    writer.init_video_stream("libx264", fps=fps)
-    for frame in range(n_frames):
-        writer.write_frame(iio.imread(os.path.join(temp_dir, f"frame_{frame:04d}.png")))
-    writer.close()
-    print(f"Video saved: {output_path}")
+        iio = None
+    if iio is not None:
+        writer = iio.imopen(output_path, "w", plugin="pyav")
+        writer.init_video_stream("libx264", fps=fps)
+        for p in frames:
+            writer.write_frame(iio.imread(p))
+        writer.close()
+        print(f"Video saved: {output_path}")
+        return True
+    if shutil.which("ffmpeg"):
+        import subprocess
+        rc = subprocess.call(["ffmpeg", "-y", "-loglevel", "error", "-framerate", str(fps), "-i", os.path.join(temp_dir, "frame_%04d.png"),
+                              "-c:v", "libx264", "-crf", "18", "-pix_fmt", "yuv420p", output_path])
+        if rc == 0:
+            print(f"Video saved: {output_path}")
+            return True
+        print(f"ffmpeg failed ({rc}) on the PNG frames; writing them into the MP4 as they are")
+    from .mp4 import png_size, write_png_mp4
+    w, h = png_size(frames[0])
+    nbytes = write_png_mp4(frames, fps, output_path, w, h)
+    print(f"Video saved: {output_path} ({n_frames} PNG-coded frames, {nbytes / 1e6:.0f} MB, lossless; no H.264 encoder in this "
+          f"environment -- re-code with: ffmpeg -i {output_path} -c:v libx264 -crf 18 -pix_fmt yuv420p out.mp4)")
     return True
 
 

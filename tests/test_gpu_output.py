@@ -169,3 +169,27 @@ def test_render_video_survives_an_encoder_that_dies(tmp_path, monkeypatch, capsy
     assert json.load(open(os.path.join(d, "progress.json")))["completed"] == list(range(40))
     text = capsys.readouterr().out
     assert "continuing with the PNG frames" in text or "falling back to the PNG frames" in text
+
+
+def test_render_video_ends_with_an_mp4_even_without_an_encoder(tmp_path, monkeypatch):
+    """No imageio / pyav and no ffmpeg (this image): render_video still leaves `output_path` behind -- the device-encoded
+    PNG frames as the samples of an MP4 track (bhr_amd/mp4.py), every sample byte for byte a frame file, and the frame
+    files decode to what the renderer quantised."""
+    import io
+    from PIL import Image
+    from bhr_amd import drivers, mp4
+    monkeypatch.setenv("PATH", str(tmp_path / "no_such_dir"))
+    out = str(tmp_path / "vid" / "clip.mp4")
+    r, _, _, _ = drivers.make_renderer(160, 96, [6, 0, 0.5], 90, n_stars=50, tex_w=256, tex_h=128)
+    drivers.render_video(r, 160, 96, n_frames=12, fps=24, output_path=out, fov=90, static_cam_pos=[6, 0, 0.5], orbit=True,
+                         orbit_degrees=30.0, assemble=True, video_stream="auto")
+    r.close()
+    info = mp4.read_samples(out)
+    assert (info["width"], info["height"], info["timescale"], info["duration"], info["object_type"]) == (160, 96, 24, 12, 0x6D)
+    d = drivers._frames_dir(out)
+    buf = open(out, "rb").read()
+    for k, (off, size) in enumerate(info["samples"]):
+        frame = open(os.path.join(d, f"frame_{k:04d}.png"), "rb").read()
+        assert buf[off:off + size] == frame
+        img = np.asarray(Image.open(io.BytesIO(frame)).convert("RGB"))
+        assert img.shape == (96, 160, 3) and img.max() > 0
