@@ -65,6 +65,7 @@ def parse():
                     help="headline = ONE frame of --workload in --gpus row blocks (strong scaling; default for --workload 8k with N > 1)")
     ap.add_argument("--tile-workload", default="8k", choices=sorted(WORKLOADS) + ["none"],
                     help="frame of the row-block (strong-scaling) leg reported beside the headline; 'none' skips it")
+    ap.add_argument("--tile-leg-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: run tile_leg on this many devices, print its dict
     ap.add_argument("--tile-tail-tiles", type=int, default=8,
                     help="at N = 1: also time ONE tile of this many alone on the device (row-block leg's single-tile budget); 0 skips it")
     ap.add_argument("--video-frames", type=int, default=300,
@@ -158,6 +159,26 @@ def tile_leg(wl, n, frames, math=None, warmup=3):
     finally:
         for t in tiles:
             t.close()
+
+
+def tile_leg_in_child(workload, n, frames, math, timeout_s=600):
+    """tile_leg in a child process: at N > 1 the auxiliary row-block leg opens contexts on every device of the node from
+    one process -- code that no run of this repository has yet executed on more than one GPU.  Should it die there (a
+    fault is not an exception), the headline of the run survives; the child's dict, or the reason it has none, is
+    reported as `tile_scaling`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--tile-leg-child", str(n), "--tile-workload", workload,
+           "--steps", str(frames), "--math", math]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                            "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the row-block leg's child process did not finish within {timeout_s} s"}
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"the row-block leg's child process ended with code {p.returncode}", "stderr_tail": p.stderr.decode(errors="replace")[-600:]}
+    return json.loads(lines[-1])
 
 
 def tile_leg_per_rank(wl, rank, world, local_rank, dist, frames, math=None, warmup=3):
@@ -303,6 +324,10 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if args.tile_leg_child > 0:                          # internal (tile_leg_in_child): no process group, one JSON dict
+        t = tile_leg(WORKLOADS[args.tile_workload], args.tile_leg_child, args.steps, math=args.math)
+        os.write(real_stdout, (json.dumps(t) + "\n").encode())
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -477,7 +502,10 @@ def main():
                 tile = {"error": f"{type(e).__name__}: {e}"}
         elif rank == 0:
             try:
-                tile = tile_leg(WORKLOADS[args.tile_workload], world, max(args.steps // 10, 10), math=args.math)
+                if world > 1 and not os.environ.get("BHR_TILE_DEVICES"):
+                    tile = tile_leg_in_child(args.tile_workload, world, max(args.steps // 10, 10), args.math)
+                else:
+                    tile = tile_leg(WORKLOADS[args.tile_workload], world, max(args.steps // 10, 10), math=args.math)
             except Exception as e:      # the headline stands on its own
                 tile = {"error": f"{type(e).__name__}: {e}"}
         D.host_barrier(dist)

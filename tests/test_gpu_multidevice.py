@@ -165,3 +165,16 @@ def test_8k_frame_in_eight_blocks_equals_one_context(hip_lib):
     np.testing.assert_array_equal(multigpu.read_gathered_u8(tiles), (np.clip(got, 0, 1) * np.float32(255)).astype(np.uint8))
     for t in tiles:
         t.close()
+
+
+def test_bench_row_block_leg_in_a_child_process(hip_lib):
+    """bench.py at N > 1 runs its auxiliary row-block leg (one process driving every device) in a child process, so that
+    a fault in code no multi-GPU node has run yet cannot take the headline with it: the child's dict comes back whole,
+    and a child that dies is reported, not raised."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    t = bench.tile_leg_in_child("fhd", 1, 4, "hybrid")
+    assert t.get("n_gpus") == 1 and t["frames"] == 4 and t["value"] > 0 and len(t["row_blocks"]) == 1, t
+    bad = bench.tile_leg_in_child("fhd", 3, 4, "hybrid")        # three devices on a one-GPU box: skipped, not an error
+    assert "skipped" in bad or "error" in bad, bad
