@@ -341,6 +341,8 @@ def main():
     backend = os.environ.get("BHR_DIST_BACKEND", "nccl")
     if "BHR_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["BHR_FORCE_DEVICE"])
+    else:
+        local_rank = D.visible_device(local_rank)        # a launcher that shows every rank only its own GPU: ordinal 0
     # BHR_DIST_FORCE=1: initialise the process group even for one rank (rehearses RCCL init + all-reduce)
     dist = D.init(backend, local_rank) if (world > 1 or os.environ.get("BHR_DIST_FORCE") == "1") else None
     red_dev = "cuda" if backend == "nccl" else "cpu"

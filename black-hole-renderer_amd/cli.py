@@ -121,6 +121,11 @@ def main(argv=None) -> int:
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if "BHR_FORCE_DEVICE" in os.environ:        # rehearsal: several ranks sharing one card
             local_rank = int(os.environ["BHR_FORCE_DEVICE"])
+        elif world > 1:                             # a launcher that shows every rank only its own GPU: ordinal 0
+            from . import _lib
+            have = int(_lib.load().bhr_device_count())
+            if have > 0 and local_rank >= have:
+                local_rank %= have
         renderer, _, _, _ = drivers.make_renderer(
             width, height, args.pov, fov, args.step_size, args.texture, args.n_stars, 2048, 1024, args.r_max, None,
             args.disk_inner_radius, args.disk_outer_radius, args.disk_tilt, args.lens_flare, args.anti_alias,

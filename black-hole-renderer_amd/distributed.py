@@ -15,6 +15,15 @@ def env_rank() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def visible_device(local_rank: int) -> int:
+    """The HIP device ordinal of this rank: LOCAL_RANK where the process sees every GPU of the node (torchrun's default),
+    ordinal 0.. where a launcher has narrowed the view (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank: the rank's
+    own GPU is then ordinal 0, and LOCAL_RANK would name a device that does not exist)."""
+    import torch
+    n = torch.cuda.device_count()           # counting devices does not initialise the GPU
+    return local_rank if n <= 0 or local_rank < n else local_rank % n
+
+
 def init(backend: str, local_rank: int = 0):
     """init_process_group with the rendezvous taken from MASTER_ADDR/MASTER_PORT (127.0.0.1 on one node)."""
     import torch
@@ -23,6 +32,7 @@ def init(backend: str, local_rank: int = 0):
         return dist
     kw = {}
     if backend == "nccl":
+        local_rank = visible_device(local_rank)
         torch.cuda.set_device(local_rank)
         kw["device_id"] = torch.device("cuda", local_rank)
     dist.init_process_group(backend=backend, **kw)
