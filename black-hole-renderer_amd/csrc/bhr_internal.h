@@ -181,7 +181,7 @@ struct bhr_ctx {
     float *d_wtab;             // bloom weights (3, R + pad)
     float *d_wext;             // unfolded weights (3, 2 R4 + 8)
     unsigned short *d_wsplit;  // bf16 x 3 weight table, 9 parts x 8 shifted copies (bloom.hip: bloom_wsplit_kernel)
-    int32_t bloom_split;       // 1: the post-pass of the current frame runs on the bf16 matrix cores (fast / hybrid arithmetic)
+    int32_t bloom_split;       // post-pass of the current frame: 0 f32 kernels, 1 bf16 matrix cores per pass where they pay (fast / hybrid), 2 both passes
     float *d_wsum_h;           // (3, W)
     float *d_wsum_v;           // (3, H)
     int32_t bloom_R, bloom_ready;

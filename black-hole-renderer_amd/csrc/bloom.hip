@@ -741,15 +741,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int ph = s0 & 7;
         const unsigned char *wl = lds_b + ph * CS + (s0 - ph) * 2;          // advances 32 bytes per chunk, -64 per tile
         const int part = 8 * CS;                                             // bytes between two parts, 3 parts per channel
-        // Chunks are whole inside or whole outside the image (H is a multiple of 16: the launcher's condition): those outside
-        // are skipped taps and are not walked.  A chunk inside the image may reach up to 15 rows past what this context's
+        // Chunks wholly outside the image are skipped taps and are not walked; the last chunk of an image whose height is
+        // not a multiple of 16 runs into the halo rows below the image, which stay zero for the life of the context
+        // (alloc_slot) -- skipped taps as well.  A chunk inside the image may reach up to 15 rows past what this context's
         // planes hold: rows outside the band of every output the wave stores (zero weights), read from the neighbouring
         // plane or from the BHR_HBLUR_PAD_ROWS zero rows around the allocation -- finite values, no predicate on any load.
         // Addresses: a wave-uniform row pointer (scalar registers, scalar arithmetic) + one per-lane offset.
         const unsigned lane_off = (unsigned)(8 * kh) * (unsigned)W + (x_ok ? x : W - 1);   // a column past the image: garbage nobody stores
         // first and last chunk start walked: inside the image, and not past the chunk that holds the last row of the planes (a
         // tile that overhangs the row block computes rows nobody stores from whatever the chunks it does walk contain)
-        const int ig_a = max(ig_first, 0), ig_b = min(min(ig_last, H - 16), (row0 + rows + R - 1) & ~15);
+        const int ig_a = max(ig_first, 0), ig_b = min(min(ig_last, (H - 1) & ~15), (row0 + rows + R - 1) & ~15);
         wl += 2 * (ig_a - ig_first);
         auto load = [&](int ig, float (&b)[3][8]) {
             const float *rowp = hblur + ((ptrdiff_t)(min(ig, ig_b) - row0 + R)) * W;     // prefetch past the last chunk: a re-read
@@ -976,9 +977,18 @@ int h_groups(int R, bool split) {
 }
 
 // kernels that need more than 48 KB of dynamic LDS are told so once
-// the bf16 kernels walk chunks of 16 that must lie whole inside or whole outside the image
-bool split_geometry_ok(const bhr_ctx *ctx) { return (ctx->cfg.width & 15) == 0 && (ctx->cfg.height & 15) == 0; }
-bool use_split(const bhr_ctx *ctx) { return ctx->bloom_split != 0 && split_geometry_ok(ctx); }
+// the bf16 H kernel walks a row in chunks of 16 pixels that must lie whole inside or whole outside it (the V kernel's chunks
+// may overhang the image: they meet zero halo rows)
+bool split_geometry_ok(const bhr_ctx *ctx) { return (ctx->cfg.width & 15) == 0; }
+// bloom_split: 0 = f32 kernels, 2 = both passes bf16 (BHR_BLOOM_SPLIT=1), 1 = each pass where it pays (fast / hybrid frames):
+// the V pass from radius 16 (fhd, R = 38: 0.034 against 0.041 ms, +1.7 % on the two-frames-in-flight headline), the H
+// pass from radius 64 (fhd: 0.031 against 0.026 -- its per-lane row streams cost more than the short convolution gains)
+bool use_split_h(const bhr_ctx *ctx) {
+    return split_geometry_ok(ctx) && (ctx->bloom_split == 2 || (ctx->bloom_split == 1 && ctx->bloom_R >= 64));
+}
+bool use_split_v(const bhr_ctx *ctx) {
+    return split_geometry_ok(ctx) && (ctx->bloom_split == 2 || (ctx->bloom_split == 1 && ctx->bloom_R >= 16));
+}
 
 // (a function attribute belongs to the device it was set on: the note is kept per (device, kernel) -- row-block tiles on the
 // eight devices of a node launch the same kernels from one process)
@@ -1035,9 +1045,9 @@ int32_t bhr_launch_bloom_h_rows(bhr_ctx *ctx, int32_t r0, int32_t r1) {
     if (r0 < 0 || r1 > ctx->rows || r0 > r1) return bhr_fail(BHR_ERR_INVALID, "bloom H: rows [%d,%d) of %d", r0, r1, ctx->rows);
     if (r0 == r1) return BHR_OK;
     const int R4 = (R + 3) & ~3;
-    const int ng = h_groups(R, use_split(ctx));
+    const int ng = h_groups(R, use_split_h(ctx));
     if (ng >= 200) {
-        if (!split_geometry_ok(ctx)) return bhr_fail(BHR_ERR_INVALID, "bloom H: the bf16 kernels need width and height to be multiples of 16 (%d x %d)", W, ctx->cfg.height);
+        if (!split_geometry_ok(ctx)) return bhr_fail(BHR_ERR_INVALID, "bloom H: the bf16 kernels need a width that is a multiple of 16 (%d x %d)", W, ctx->cfg.height);
         const int T = ng - 200;
         dim3 mgrid((W + 32 * T - 1) / (32 * T), (r1 - r0 + 127) / 128), mblock(256);
         const size_t mlds = (size_t)72 * wsplit_cs(R);
@@ -1078,7 +1088,7 @@ int32_t bhr_launch_bloom_h_rows(bhr_ctx *ctx, int32_t r0, int32_t r1) {
 
 int32_t bhr_launch_bloom_h(bhr_ctx *ctx) { return bhr_launch_bloom_h_rows(ctx, 0, ctx->rows); }
 
-int32_t bhr_bloom_v_tile_rows(bhr_ctx *ctx) { return v_rows_per_block(v_geometry(ctx->bloom_R, ctx->rows, use_split(ctx))); }
+int32_t bhr_bloom_v_tile_rows(bhr_ctx *ctx) { return v_rows_per_block(v_geometry(ctx->bloom_R, ctx->rows, use_split_v(ctx))); }
 
 // V pass + combine over the local rows [r0, r1); u8_out != nullptr: also the quantised final rows ((rows, W, 3) u8 base)
 int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, int32_t r1, uint8_t *u8_out) {
@@ -1087,9 +1097,9 @@ int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, in
     if (rc) return rc;
     if (r0 < 0 || r1 > ctx->rows || r0 > r1) return bhr_fail(BHR_ERR_INVALID, "bloom V: rows [%d,%d) of %d", r0, r1, ctx->rows);
     if (r0 == r1) return BHR_OK;
-    const VGeom g = v_geometry(R, ctx->rows, use_split(ctx));
+    const VGeom g = v_geometry(R, ctx->rows, use_split_v(ctx));
     if (g.v2 == 3) {
-        if (!split_geometry_ok(ctx)) return bhr_fail(BHR_ERR_INVALID, "bloom V: the bf16 kernels need width and height to be multiples of 16 (%d x %d)", W, H);
+        if (!split_geometry_ok(ctx)) return bhr_fail(BHR_ERR_INVALID, "bloom V: the bf16 kernels need a width that is a multiple of 16 (%d x %d)", W, H);
         const int vb = 32 * g.groups;
         dim3 mgrid((W + 127) / 128, (r1 - r0 + vb - 1) / vb), mblock(256);
         const size_t mlds = with_bloom ? (size_t)72 * wsplit_cs(R) : 0;

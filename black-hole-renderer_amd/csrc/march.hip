@@ -1249,11 +1249,11 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         // list form run strict
         if (mode == BHR_MATH_HYBRID && (ctx->disk_source != BHR_DISK_TEXTURE || (flags & BHR_PERSISTENT))) mode = BHR_MATH_STRICT;
         // the frame's post-pass follows its march: exact f32 chains under strict, the bf16 x 3 matrix-core kernels (bloom.hip)
-        // under fast and hybrid where they pay (radius >= 64: 4k and up); BHR_BLOOM_SPLIT=0 / 1 forces either for every arithmetic
+        // under fast and hybrid where they pay (V pass from radius 16, H pass from radius 64); BHR_BLOOM_SPLIT=0 / 1 forces either for every arithmetic
         {
             const char *e = getenv("BHR_BLOOM_SPLIT");
             const int forced = e ? (atoi(e) != 0 ? 1 : 0) : -1;
-            ctx->bloom_split = forced >= 0 ? forced : (mode != BHR_MATH_STRICT && ctx->bloom_R >= 64);
+            ctx->bloom_split = forced == 1 ? 2 : forced == 0 ? 0 : (mode != BHR_MATH_STRICT ? 1 : 0);   // 1: per pass, by radius (bloom.hip)
         }
         if (mode == BHR_MATH_HYBRID) return bhr_launch_march_hybrid(ctx, cam, flags);
         if (mode == BHR_MATH_STRICT) return bhr_launch_march_strict(ctx, cam, flags);

@@ -103,22 +103,41 @@ def test_split_bloom_row_blocks_equal_one_context_bit_for_bit(hip_lib):
         t.close()
 
 
-def test_split_needs_multiples_of_16_and_falls_back(hip_lib):
-    """fhd (height 1080 = 16 x 67.5, radius 38): the fast arithmetic keeps the f32 post-pass there"""
+def test_fhd_fast_keeps_the_f32_post_pass_and_odd_widths_fall_back(hip_lib, monkeypatch):
+    """A small frame (radius 6 < 64, like fhd's 38): the fast arithmetic keeps the f32 post-pass; a width that is not a multiple of 16 keeps it even
+    when the bf16 pass is forced on by the environment switch (the H kernel's chunks must tile a row)."""
     from bhr_amd import HipRenderer, _lib
     s = scenes.SCENES["default"]
     sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
-    a = HipRenderer(s["width"], s["height"], sky, tex, math="fast", **s["kw"])
-    b = HipRenderer(s["width"], s["height"], sky, tex, math="strict", **s["kw"])
-    a.render_async([6, 0, 0.5], 90)
-    disk, bg = a.read_layer(_lib.LAYER_DISK), a.read_layer(_lib.LAYER_BG)
-    b.render_async([6, 0, 0.5], 90, skip_bloom=True)
-    b.write_layer(_lib.LAYER_DISK, disk)
-    b.write_layer(_lib.LAYER_BG, bg)
-    b.bloom_only()
-    np.testing.assert_array_equal(a.read_layer(_lib.LAYER_BLUR), b.read_layer(_lib.LAYER_BLUR))
-    a.close()
-    b.close()
+    for (w, h), force in (((s["width"], s["height"]), False), ((200, 120), True)):
+        if force:
+            monkeypatch.setenv("BHR_BLOOM_SPLIT", "1")
+        a = HipRenderer(w, h, sky, tex, math="fast", **s["kw"])
+        b = HipRenderer(w, h, sky, tex, math="strict", **s["kw"])
+        a.render_async([6, 0, 0.5], 90)
+        disk, bg = a.read_layer(_lib.LAYER_DISK), a.read_layer(_lib.LAYER_BG)
+        monkeypatch.delenv("BHR_BLOOM_SPLIT", raising=False)
+        b.render_async([6, 0, 0.5], 90, skip_bloom=True)
+        b.write_layer(_lib.LAYER_DISK, disk)
+        b.write_layer(_lib.LAYER_BG, bg)
+        b.bloom_only()
+        np.testing.assert_array_equal(a.read_layer(_lib.LAYER_BLUR), b.read_layer(_lib.LAYER_BLUR))
+        a.close()
+        b.close()
+
+
+def test_fhd_fast_frames_take_the_bf16_v_pass_only(hip_lib):
+    """1920x1080 (radius 38: between the V pass's threshold of 16 and the H pass's 64): a fast frame's post-pass differs
+    from the exact kernels' by the bf16 V pass alone -- within 3e-6 -- and equals an f32 H pass followed by a forced bf16 V."""
+    from bhr_amd import HipRenderer, _lib
+    sky, tex = scenes.analytic_skybox(128, 256), scenes.noisy_disk(256, 1024)
+    r = HipRenderer(1920, 1080, sky, tex, math="fast", frame_slots=1, **KW)
+    r.render_async(CAM, FOV)
+    disk, bg = r.read_layer(_lib.LAYER_DISK), r.read_layer(_lib.LAYER_BG)
+    (blur_s, final_s), (blur_x, final_x) = _both_blooms(r, disk, bg)
+    r.close()
+    d = np.abs(blur_s - blur_x)
+    assert 0 < d.max() <= 3e-6 and np.abs(final_s - final_x).max() <= 3e-6, d.max()
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -129,7 +148,7 @@ def test_random_row_blocks_and_sizes_split_bloom(seed, hip_lib, monkeypatch):
     from bhr_amd import HipRenderer, multigpu
     rng = np.random.default_rng(100 + seed)
     # widths that are multiples of 16 but not of 32 or 128 leave partial column strips / output tiles at the right edge
-    W, H = [(640, 400), (320, 208), (960, 544), (1280, 720), (400, 208), (1008, 560)][seed % 6]
+    W, H = [(640, 400), (320, 208), (960, 540), (1280, 720), (400, 205), (1008, 567)][seed % 6]      # heights: any
     monkeypatch.setenv("BHR_BLOOM_SPLIT", "1")
     if seed % 2:
         monkeypatch.setenv("BHR_BLOOM_H", "bf16x2")
