@@ -15,9 +15,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(tmp_path, world, gather, frames=3, math="strict"):
+def _run(tmp_path, world, gather, frames=3, math="strict", size=None):
     shm = "bhr_test_" + uuid.uuid4().hex[:12]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if size:
+        env["BHR_TEST_SIZE"] = f"{size[0]}x{size[1]}"
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "ipc_tile_worker.py"), str(tmp_path), str(k), str(world), shm,
                                gather, str(frames), math], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for k in range(world)]
@@ -49,4 +51,17 @@ def test_one_process_per_tile_equals_one_context(tmp_path, world, gather, hip_li
         want = full.read_final_u8()
         d = np.abs(got.astype(np.int32) - want.astype(np.int32))
         assert d.max() <= 1 and (d > 0).mean() < 1e-4, (d.max(), (d > 0).mean())   # 1e-6 of bloom rounding across a truncation
+    full.close()
+
+
+def test_one_process_per_tile_hybrid_with_the_bf16_v_pass(tmp_path, hip_lib):
+    """960x544 (bloom radius 19), hybrid: every process marches its block's strict and fast tile lists and runs the bf16 V
+    pass over halo rows that arrived through IPC handles -- the same bits as one hybrid context."""
+    from bhr_amd import HipRenderer
+    got, steps = _run(tmp_path, 3, "peer", math="hybrid", size=(960, 544))
+    s = scenes.SCENES["default"]
+    full = HipRenderer(960, 544, scenes.analytic_skybox(), scenes.noisy_disk(), frame_slots=1, math="hybrid", **s["kw"])
+    ref = full.render(s["cam_pos"], s["fov"])
+    assert steps == full.counters()["ray_steps"]
+    np.testing.assert_array_equal(got, ref)
     full.close()
