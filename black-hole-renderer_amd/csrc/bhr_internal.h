@@ -33,10 +33,18 @@
 #define BHR_STEP_CELL (BHR_STEP_LANES * BHR_STEP_STRIDE)
 
 // hybrid march: guard bands around the algorithm's switches; a lane inside one is re-marched strict (march.hip: march_tile_hybrid)
+#ifndef BHR_LOD_GUARD
 #define BHR_LOD_GUARD 2e-3f         // |lod - level boundary| (the fast differentials are good to ~1e-5 in lod away from the ring)
+#endif
+#ifndef BHR_R2_GUARD
 #define BHR_R2_GUARD 4e-5f          // |r^2 - r_term^2| / r_term^2 of a plane-crossing step (fast positions are good to ~1e-6 relative)
+#endif
+#ifndef BHR_EDGE_GUARD
 #define BHR_EDGE_GUARD 2e-5f        // |hit_r - r_edge| / r_edge at the disk's edges
+#endif
+#ifndef BHR_F_GUARD
 #define BHR_F_GUARD 2e-6f           // |plane function at new_pos| / |new_pos|: a step that ends on the disk plane
+#endif
 #define BHR_FLUSH_COST 5u            // cost of one wave-wide shading pass in wave-steps (row-cost profile)
 #define BHR_VOLUME_OPAQUE 0.9999f   // finite-thickness disk: accumulated opacity at which a ray stops sampling
 

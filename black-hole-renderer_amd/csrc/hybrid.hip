@@ -26,6 +26,7 @@
 namespace {
 
 constexpr double B_CRIT = 2.598076211353316;   // 3 sqrt(3) / 2 r_s, r_s = 1
+constexpr double PLANE_SIN = 0.02;             // orbital planes within 1.1 degrees of the disk plane march strict (classify)
 
 constexpr int HYBRID_LISTS = 3;   // base lists a march can be launched over: whole block, halo bands, the rest (bhr_march_part.id)
 
@@ -39,7 +40,7 @@ struct SlotLists {
     int32_t *d_list;       // the base list partitioned: strict tiles first (launch order kept), then the fast ones
     int32_t *h_pinned;
     hipEvent_t copied;     // the last upload from h_pinned
-    double key[8];
+    double key[12];
     int32_t n_strict, base_n, valid, pending;
 };
 
@@ -48,12 +49,12 @@ struct Hybrid {
     FixList fix[BHR_MAX_FRAME_SLOTS];
     // last classification on the host
     std::vector<uint8_t> strict;   // per tile of the row block: marched strict
-    double key[8];
+    double key[12];
     int32_t n_strict, valid;
     double lo, hi;                 // band below / above b_c (BHR_HYBRID_BAND="lo,hi")
 };
 
-void view_key(const bhr_camera *cam, double lo, double hi, double key[8]) {
+void view_key(const bhr_camera *cam, double lo, double hi, double tilt_deg, double key[12]) {
     double p[3], r2 = 0, pf = 0, pr = 0, pu = 0;
     for (int k = 0; k < 3; ++k) {
         p[k] = cam->pos[k];
@@ -64,14 +65,28 @@ void view_key(const bhr_camera *cam, double lo, double hi, double key[8]) {
     }
     key[0] = sqrt(r2); key[1] = pf; key[2] = pr; key[3] = pu;
     key[4] = cam->pixel_width; key[5] = cam->pixel_height; key[6] = lo; key[7] = hi;
+    // the in-plane family (classify) only exists for a camera within PLANE_SIN of the disk plane as seen from the hole: the
+    // view's orientation against the disk normal enters the key there and nowhere else (an orbit about a tilted disk keeps
+    // its cached lists for all the frames in which it is clear of the plane)
+    const double tilt = tilt_deg * 3.14159265358979323846 / 180.0;
+    const double nrm[3] = {0.0, -sin(tilt), cos(tilt)};
+    double pn = 0, fn = 0, rn = 0, un = 0;
+    for (int k = 0; k < 3; ++k) {
+        pn += p[k] * nrm[k];
+        fn += (double)cam->forward[k] * nrm[k];
+        rn += (double)cam->right[k] * nrm[k];
+        un += (double)cam->up[k] * nrm[k];
+    }
+    const bool near_plane = fabs(pn) <= (PLANE_SIN * 1.05) * sqrt(r2);
+    key[8] = near_plane ? pn : 1e30; key[9] = near_plane ? fn : 0; key[10] = near_plane ? rn : 0; key[11] = near_plane ? un : 0;
 }
 
 // the classification only depends on the view through the key; geometry within 1e-5 (absolute, in r_s) of the cached
 // one moves b by less than the 1e-3 the band is padded with
-bool same_view(const double a[8], const double b[8]) {
+bool same_view(const double a[12], const double b[12]) {
     for (int k = 0; k < 4; ++k)
         if (fabs(a[k] - b[k]) > 1e-5) return false;
-    for (int k = 4; k < 8; ++k)
+    for (int k = 4; k < 12; ++k)
         if (a[k] != b[k]) return false;
     return true;
 }
@@ -90,6 +105,16 @@ void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, s
     const int gx_n = tiles_x + 1, gy_n = tiles_y + 1;
     std::vector<float> bgrid((size_t)gx_n * gy_n);
     std::vector<uint8_t> outgoing((size_t)gx_n * gy_n);
+    // A second unstable family: rays whose orbital plane all but coincides with the disk plane (a camera within a degree of
+    // the disk plane sees them as a line through the hole's image).  The plane function is ~0 all along such a ray -- where it
+    // "crosses" is decided by rounding, in the reference's arithmetic as in any other -- and the fast kernel's basis (g1 =
+    // line of nodes of the two planes) is ill defined.  sgrid = sin of the angle between the planes, up = side of the disk
+    // plane the ray leaves the camera on; tiles that may hold a ray with sgrid < PLANE_SIN go to the strict list.
+    const double tilt = (double)ctx->cfg.disk_tilt_deg * 3.14159265358979323846 / 180.0;
+    const double nrm[3] = {0.0, -sin(tilt), cos(tilt)};                      // z cos(tilt) - y sin(tilt) = 0
+    const double cpn = cp[0] * nrm[0] + cp[1] * nrm[1] + cp[2] * nrm[2];
+    std::vector<float> sgrid((size_t)gx_n * gy_n), blgrid((size_t)gx_n * gy_n);
+    std::vector<uint8_t> up((size_t)gx_n * gy_n);
     for (int gy = 0; gy < gy_n; ++gy) {
         const double y = (double)row0 + (double)(gy * 8 < rows ? gy * 8 : rows) - 0.5;
         for (int gx = 0; gx < gx_n; ++gx) {
@@ -101,6 +126,16 @@ void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, s
                 pd += cp[k] * d[k];
             }
             pd /= sqrt(dn);
+            {
+                const double inv_d = 1.0 / sqrt(dn);
+                double dnn = 0, v2 = 0;
+                for (int k = 0; k < 3; ++k) dnn += d[k] * inv_d * nrm[k];
+                for (int k = 0; k < 3; ++k) { const double v = d[k] * inv_d * cpn - cp[k] * dnn; v2 += v * v; }   // (cp x d) x n
+                const double bl = sqrt(r0sq - pd * pd > 1e-18 ? r0sq - pd * pd : 1e-18);
+                sgrid[(size_t)gy * gx_n + gx] = (float)(sqrt(v2) / bl);
+                blgrid[(size_t)gy * gx_n + gx] = (float)bl;
+                up[(size_t)gy * gx_n + gx] = dnn > 0;
+            }
             // The orbit is fixed by the first integral of the path equation the reference integrates (u'' + u = 3/2 u^2,
             // u = 1 / r; render.py:2928-2934 is its Cartesian form):  u'^2 + u^2 - u^3 = 1 / b_l^2 - 1 / r0^3  with the LOCAL
             // moment b_l = |pos x dir| -- not by b_l itself.  The ray whirls at the photon sphere when that integral is
@@ -121,6 +156,23 @@ void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, s
             const float c[4] = {bgrid[g], bgrid[g + 1], bgrid[g + gx_n], bgrid[g + gx_n + 1]};
             float bmin = c[0], bmax = c[0];
             for (int k = 1; k < 4; ++k) { bmin = c[k] < bmin ? c[k] : bmin; bmax = c[k] > bmax ? c[k] : bmax; }
+            {
+                // sin^2 of the angle between the planes ~ (cam . n / b_l)^2 + (|cam| (d . n) / b_l)^2: the family is a thin wedge
+                // around the line d . n = 0, present only where |cam . n| / b_l is small.  A tile belongs to it when that line
+                // runs through it (its corners leave the camera on both sides of the disk plane) or a corner lies in the wedge.
+                const size_t q[4] = {g, g + 1, g + gx_n, g + gx_n + 1};
+                float smin = sgrid[q[0]], blmax = blgrid[q[0]];
+                int ups = 0;
+                for (int k = 0; k < 4; ++k) {
+                    smin = sgrid[q[k]] < smin ? sgrid[q[k]] : smin;
+                    blmax = blgrid[q[k]] > blmax ? blgrid[q[k]] : blmax;
+                    ups += up[q[k]];
+                }
+                if (fabs(cpn) < PLANE_SIN * (double)blmax && ((ups != 0 && ups != 4) || (double)smin < 1.5 * PLANE_SIN)) {
+                    strict[(size_t)ty * tiles_x + tx] = 1;
+                    continue;
+                }
+            }
             if (far_cam && outgoing[g] && outgoing[g + 1] && outgoing[g + gx_n] && outgoing[g + gx_n + 1]) continue;
             // b grows with the distance from the hole's image in a convex sense (the field of view stays under 180 degrees): its
             // maximum over the tile is at a corner, its minimum may lie on an edge -- pad by the tile's own span
@@ -183,8 +235,8 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     const int base_n = base.active ? base.n : ctx->tile_order_n;
     const int id = base.active ? base.id : 0;
     if (id < 0 || id >= HYBRID_LISTS || !base_list) return bhr_fail(BHR_ERR_INVALID, "hybrid march: bad base list %d", id);
-    double key[8];
-    view_key(cam, h->lo, h->hi, key);
+    double key[12];
+    view_key(cam, h->lo, h->hi, (double)ctx->cfg.disk_tilt_deg, key);
     if (!h->valid || !same_view(h->key, key)) {
         classify(ctx, cam, h->lo, h->hi, h->strict);
         int n = 0;

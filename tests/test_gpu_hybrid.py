@@ -233,3 +233,28 @@ def test_row_costs_split_by_arithmetic_and_hybrid_balanced_blocks(hip_lib):
     mid_f = sum(b[1] - b[0] for b in bf[2:6])
     mid_h = sum(b[1] - b[0] for b in bh[2:6])
     assert mid_h < mid_f, (bf, bh)                     # the four middle blocks (the ring's) get fewer rows under hybrid costs
+
+
+@pytest.mark.parametrize("cam,tilt", [([6.0, 0.0, 0.0], 0.0), ([-10.27977657706746, 3.4882456957730086, 5.652677980932753], 58.41173651690485)])
+def test_edge_on_camera_marches_the_in_plane_rays_strict(cam, tilt, hip_lib):
+    """A camera in the disk plane (exactly, or by 0.01 r_s of 12 as the fuzzed view that found this): the rays whose orbital
+    plane all but coincides with the disk plane -- a line through the hole's image -- have a plane function of ~0 all along,
+    their "crossings" are decided by rounding in any arithmetic, and the fast kernel's line-of-nodes basis is ill defined.
+    Their tiles go to the strict list: hybrid == strict on them, and the frame stays inside the certified margin."""
+    from bhr_amd import HipRenderer, _lib, scenes
+    W, H = 640, 360
+    sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
+    kw = dict(step_size=0.1, r_max=25.0, r_disk_inner=2.35, r_disk_outer=20.0, disk_tilt=tilt)
+    r = HipRenderer(W, H, sky, tex, math="hybrid", **kw)
+    lay = {}
+    for math in ("hybrid", "strict"):
+        r.render_async(cam, 100.0, skip_bloom=True, math=math)
+        lay[math] = (r.read_layer(_lib.LAYER_BG), r.read_layer(_lib.LAYER_DISK))
+        if math == "hybrid":
+            info = r.hybrid_info()
+    r.close()
+    assert info["strict_tiles"] >= W // 8                   # at least the row (or diagonal) of tiles the line runs through
+    for a, b in zip(lay["hybrid"], lay["strict"]):
+        d = np.abs(a - b).max(axis=2)
+        e = np.sqrt(np.mean((a.astype(np.float64) - b) ** 2, axis=(0, 1)))
+        assert (e <= 3e-5).all() and int((d > 1e-2).sum()) == 0, (e, int((d > 1e-2).sum()), info)
