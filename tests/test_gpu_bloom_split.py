@@ -126,6 +126,42 @@ def test_fhd_fast_keeps_the_f32_post_pass_and_odd_widths_fall_back(hip_lib, monk
         b.close()
 
 
+def test_split_bloom_is_exactly_scale_invariant_over_the_f32_range(hip_lib, monkeypatch):
+    """Cutting an f32 value into three bf16 parts commutes with powers of two, and so does every product and sum of the
+    kernels: bloom(2^k x) == 2^k bloom(x) bit for bit from 2^-60 to 2^40 (no part under- or overflows anywhere near the
+    values a frame holds); a layer of HDR spikes on a faint floor stays within 3e-6 of the exact kernels RELATIVE to the
+    local result."""
+    from bhr_amd import HipRenderer, _lib
+    monkeypatch.setenv("BHR_BLOOM_SPLIT", "1")
+    W, H = 1280, 720
+    r = HipRenderer(W, H, np.zeros((16, 32, 3), np.float32), np.zeros((32, 64, 4), np.float32), math="fast", frame_slots=1,
+                    **dict(KW, step_size=0.5))
+    r.render_async(CAM, FOV, skip_bloom=True)
+    r.write_layer(_lib.LAYER_BG, np.zeros((H, W, 3), np.float32))
+
+    def bloom(x):
+        r.write_layer(_lib.LAYER_DISK, x)
+        r.bloom_only()
+        return r.read_layer(_lib.LAYER_BLUR)
+
+    rng = np.random.default_rng(3)
+    x = (rng.random((H, W, 3), dtype=np.float32) * 1e-3).astype(np.float32)
+    ys, xs = rng.integers(0, H, 400), rng.integers(0, W, 400)
+    x[ys, xs] = rng.random((400, 3), dtype=np.float32) * 50.0
+    base = bloom(x)
+    assert np.isfinite(base).all() and base.max() > 0.01
+    for k in (-60, -20, 14, 40):
+        sc = np.float32(2.0) ** k
+        np.testing.assert_array_equal(bloom(x * sc), base * sc, err_msg=f"2^{k}")
+    monkeypatch.setenv("BHR_BLOOM_SPLIT", "0")
+    r.render_async(CAM, FOV, skip_bloom=True, math="strict")
+    exact = bloom(x)
+    r.close()
+    assert not np.array_equal(exact, base)
+    rel = np.abs(base - exact) / np.maximum(exact, 1e-12)
+    assert rel.max() <= 3e-6, rel.max()
+
+
 def test_fhd_fast_frames_take_the_bf16_v_pass_only(hip_lib):
     """1920x1080 (radius 38: between the V pass's threshold of 16 and the H pass's 64): a fast frame's post-pass differs
     from the exact kernels' by the bf16 V pass alone -- within 3e-6 -- and equals an f32 H pass followed by a forced bf16 V."""
