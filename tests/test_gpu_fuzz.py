@@ -112,3 +112,29 @@ def test_telephoto_views_hybrid_within_the_f32_noise_of_the_march(k, n, seed, or
     assert int((np.abs(lay["hybrid"] - lay["strict"]).max(axis=2) > 0.05).sum()) == 0
     assert e_hs <= max(6e-5, 1.5 * e_s64), (e_hs, e_s64)
     assert e_h64 <= max(6e-5, 1.5 * e_s64), (e_h64, e_s64)           # and no further from binary64 than strict is, x 1.5
+
+
+@pytest.mark.parametrize("k", range(0, 24, 3))
+def test_random_view_hybrid_row_blocks_equal_one_context(k, hip_lib):
+    """Eight of the fuzzed views as hybrid frames cut into three uneven row blocks: every block classifies its own tiles
+    (band, in-plane wedge), marches its two lists, repairs where the view asks for it, blooms over exchanged halo rows -- the
+    gathered frame equals the frame of one context bit for bit, and the ray-step totals agree."""
+    from bhr_amd import HipRenderer, multigpu
+    c = _cases()[k]
+    w, h = 320, 208
+    rng = np.random.default_rng(900 + k)
+    # cuts on multiples of 8, as balanced_row_blocks makes them: the strict / fast choice is per 8x8 tile of the block's own
+    # tiling, and only then is that the tiling of the whole frame
+    cuts = [0] + sorted(8 * int(v) for v in rng.choice(np.arange(1, h // 8 - 1), size=2, replace=False)) + [h]
+    sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
+    full = HipRenderer(w, h, sky, tex, math="hybrid", frame_slots=1, **c["kw"])
+    ref = full.render(c["cam"], c["fov"], frame=c["frame"])
+    steps = full.counters()["ray_steps"]
+    full.close()
+    tiles = [HipRenderer(w, h, sky, tex, rows=(cuts[q], cuts[q + 1]), math="hybrid", frame_slots=1, **c["kw"]) for q in range(3)]
+    for sched in ("serial", "pipelined"):
+        multigpu.group_render(tiles, c["cam"], c["fov"], frame=c["frame"], gather="peer", schedule=sched)
+        np.testing.assert_array_equal(multigpu.read_gathered(tiles), ref, err_msg=f"case {k} cuts {cuts} {sched}: {c}")
+    assert sum(t.counters()["ray_steps"] for t in tiles) == steps
+    for t in tiles:
+        t.close()
