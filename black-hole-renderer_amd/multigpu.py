@@ -28,6 +28,15 @@ def row_blocks(height: int, n: int) -> List[Tuple[int, int]]:
     return cuts
 
 
+def aligned_row_blocks(height: int, n: int, quantum: int = 8) -> List[Tuple[int, int]]:
+    """The even cut with its cuts on multiples of ``quantum`` rows (the march's 8x8 tiles: a block whose first row is not a
+    multiple of 8 tiles its rows differently from the whole frame, and the hybrid arithmetic chooses strict / fast per
+    tile); plain row_blocks where the frame is too small for that."""
+    if n * quantum > height:
+        return row_blocks(height, n)
+    return balanced_row_blocks(height, n, np.ones((height + quantum - 1) // quantum), quantum, quantum)
+
+
 def balanced_row_blocks(height: int, n: int, band_costs: Sequence[float], band_rows: int, quantum: int = 8,
                         fixed_cost_per_row: float = 0.0) -> List[Tuple[int, int]]:
     """n contiguous row blocks of about equal COST.  ``band_costs[k]`` is the cost (ray-steps) of rows
@@ -234,7 +243,7 @@ def render_image_tiled(width, height, cam_pos, fov, gpus, lens_flare=False, devi
     devices = list(range(gpus)) if devices is None else list(devices)
     if len(devices) != gpus:
         raise ValueError(f"{gpus} row blocks need {gpus} device ordinals, got {devices}")
-    blocks = row_blocks(height, gpus)
+    blocks = aligned_row_blocks(height, gpus)
     if balance and gpus > 1 and height >= 64 * gpus:
         per_row, band_rows = probe_row_costs(width, height, cam_pos, fov, device_index=devices[0], math=math, **kw)
         blocks = balanced_row_blocks(height, gpus, per_row, band_rows, fixed_cost_per_row=0.1 * float(per_row.mean()))

@@ -36,7 +36,7 @@ def plan_blocks(wl: dict, n: int, device_index: int = 0, balance: bool = True, m
     from . import multigpu
     W, H = wl["width"], wl["height"]
     kw = dict(step_size=wl["step_size"], r_max=10.0, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=wl["disk_tilt"])
-    blocks = multigpu.row_blocks(H, n)
+    blocks = multigpu.aligned_row_blocks(H, n)
     if balance and n > 1 and H >= 64 * n:
         per_row, band_rows = multigpu.probe_row_costs(W, H, wl["cam_pos"], wl["fov"], device_index=device_index, math=math, **kw)
         blocks = multigpu.balanced_row_blocks(H, n, per_row, band_rows, fixed_cost_per_row=0.1 * float(per_row.mean()))
