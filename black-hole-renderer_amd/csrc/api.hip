@@ -307,6 +307,7 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     ctx->cfg = *cfg;
     ctx->rows = cfg->row1 - cfg->row0;
     ctx->bloom_R = (int32_t)(cfg->width * 0.02);  // int(self.width * 0.02), render.py:3914
+    ctx->mip_lds_from = -1;
 
     auto bail = [&](int32_t rc) { bhr_destroy(ctx); return rc; };
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipSetDevice(%d) failed", cfg->device));
@@ -789,6 +790,8 @@ int32_t bhr_selftest(bhr_ctx *ctx, uint64_t out[4]) {
     (void)hipFree(d);
     return rc;
 }
+
+int32_t bhr_mip_lds_level(bhr_ctx *ctx) { return ctx ? ctx->mip_lds_from : -1; }
 
 int32_t bhr_get_row_costs(bhr_ctx *ctx, uint64_t *out, int32_t n) {
     if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_get_row_costs: bad argument");

@@ -89,6 +89,7 @@ struct BhrMarchArgs {
     int32_t n_tiles;         // 8x8 pixel tiles in the row block
     int32_t tiles_x;
     int32_t n_list;          // launch slots of this launch (= n_tiles, or the length of a hybrid / row-band sub-list)
+    int32_t mip_lds_from;    // BHR_MIP_LDS: mip levels mip_lds_from .. BHR_NUM_MIP_LEVELS - 1 are staged in LDS (march_tile_mipstaged_kernel); -1: none
     unsigned int *fix_count; // hybrid march: pixels the guard kernel handed over to the strict fix kernel
     int32_t *fix_list;
     int32_t fix_cap;
@@ -189,6 +190,7 @@ struct bhr_ctx {
     float *d_wtab;             // bloom weights (3, R + pad)
     float *d_wext;             // unfolded weights (3, 2 R4 + 8)
     unsigned short *d_wsplit;  // bf16 x 3 weight table, 9 parts x 8 shifted copies (bloom.hip: bloom_wsplit_kernel)
+    int32_t mip_lds_from;      // first mip level the last anti-aliased fast march staged in LDS (BHR_MIP_LDS), -1: none
     int32_t bloom_split;       // post-pass of the current frame: 0 f32 kernels, 1 bf16 matrix cores per pass where they pay (fast / hybrid), 2 both passes
     float *d_wsum_h;           // (3, W)
     float *d_wsum_v;           // (3, H)

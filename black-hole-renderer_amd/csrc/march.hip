@@ -186,8 +186,10 @@ __device__ __forceinline__ V3 sample_skybox(const BhrScene &sc, V3 d) {
 // ---- _sample_disk / _sample_disk_mip (render.py:2568-2637) -------------------
 // lod_i = 0 reproduces _sample_disk exactly (level 0 of the mip stack is the
 // texture itself and n / 2^0 = n).
+// `staged` (SRC == 3 kernels): the packed levels staged_from .. last of the mip stack, copied into LDS at block start
 __device__ __forceinline__ float4 sample_disk_level(const BhrScene &sc, float hit_x, float hit_y, float r_inner,
-                                                    float r_outer, float t_offset, int lod_i) {
+                                                    float r_outer, float t_offset, int lod_i,
+                                                    const float4 *staged = nullptr, int staged_from = 1 << 30) {
     float r = sqrtf(hit_x * hit_x + hit_y * hit_y);
     float phi = atan2f(hit_y, hit_x);
     float r_safe = fmaxf(r, 1e-3f);
@@ -211,7 +213,7 @@ __device__ __forceinline__ float4 sample_disk_level(const BhrScene &sc, float hi
     int vmax = (int)(tex_h_lod - 1.0f);
     int v0_h = min(max(v0, 0), vmax);
     int v1_h = min(max(v0 + 1, 0), vmax);
-    const float4 *t = sc.mips + sc.mip_off[lod_i];
+    const float4 *t = lod_i >= staged_from ? staged + (sc.mip_off[lod_i] - sc.mip_off[staged_from]) : sc.mips + sc.mip_off[lod_i];
     const int stride = sc.mip_w[lod_i];
     float4 c00 = t[(size_t)v0_h * stride + u0_w];
     float4 c10 = t[(size_t)v0_h * stride + u1_w];
@@ -345,6 +347,7 @@ struct Pending {
 // lanes, consecutive words): they are touched a handful of times per ray, and in registers they cost the AA
 // kernel a wave of occupancy (128 -> 149 VGPRs).
 __shared__ float g_park[2][9][256];
+extern __shared__ __attribute__((aligned(16))) float4 g_mip_lds[];   // SRC == 3: the coarse mip levels of the disk texture (dynamic)
 template <bool DIFF>
 __device__ __forceinline__ void park_store(int slot, const Pending<DIFF> &h) {
     const int t = threadIdx.x;
@@ -410,7 +413,8 @@ __device__ __forceinline__ void shade_hit(const BhrMarchArgs &a, Shade &sh, floa
     // SRC == 1 is a separate kernel instantiation: the binary64 model code (and its registers) never
     // touches the texture kernels
     float4 rgba = SRC == 1 ? disk_v2_rgba(a, hit_x, hit_y)
-                      : sample_disk_level(a.sc, hit_x, hit_y, a.r_inner, a.r_outer, a.t_offset, lod_i);
+                  : SRC == 3 ? sample_disk_level(a.sc, hit_x, hit_y, a.r_inner, a.r_outer, a.t_offset, lod_i, g_mip_lds, a.mip_lds_from)
+                             : sample_disk_level(a.sc, hit_x, hit_y, a.r_inner, a.r_outer, a.t_offset, lod_i);
     float base_alpha = fminf(rgba.w, 0.999f);
     float disk_alpha = 1.0f - powf(1.0f - base_alpha, BHR_DISK_ALPHA_GAIN);
     V3 col = apply_g_factor(a, mk(rgba.x, rgba.y, rgba.z), mk(hit_x, hit_y, hit_z), hit_r, to_cam);
@@ -1011,6 +1015,21 @@ __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
 }
 
 #if !BHR_MARCH_STRICT
+// BASELINE.json's north star asks for "mipmap levels staged through LDS".  Opt-in (BHR_MIP_LDS=1, fast arithmetic,
+// anti-aliased views): every block copies the coarse levels of the packed mip stack -- as many of levels 3, 2, 1 as fit
+// 48 KB -- into LDS before it marches, and _sample_disk_mip reads those levels from there.  Not the default, by
+// measurement: the texture gathers are cache resident (FETCH_SIZE 0.36x the algorithmic bytes) and the kernel
+// is issue bound, while 48 KB of LDS leave two blocks per CU; and the BASELINE textures' level 3 (4.8 MB at 4k) does not
+// fit any LDS -- the launcher falls back to the plain kernel when nothing fits.
+__global__ __launch_bounds__(256) void march_tile_mipstaged_kernel(BhrMarchArgs a) {
+    const int from = a.mip_lds_from;
+    const int n = a.sc.mip_off[3] + a.sc.mip_h[3] * a.sc.mip_w[3] - a.sc.mip_off[from];     // levels from .. 3: the LOD is clamped to 3
+    const float4 *src = a.sc.mips + a.sc.mip_off[from];
+    for (int k = threadIdx.x; k < n; k += 256) g_mip_lds[k] = src[k];
+    __syncthreads();
+    march_tile_body<true, 3>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+}
+
 template <bool DIFF>
 __global__ __launch_bounds__(256) void march_tile_guard_kernel(BhrMarchArgs a) {
     march_tile_body<DIFF, 0, true>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
@@ -1329,6 +1348,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     a.n_tiles = a.tiles_x * ((ctx->rows + 7) / 8);
     a.n_list = a.n_tiles;
     a.fix_count = ctx->fix_count;
+    a.mip_lds_from = -1;
     a.fix_list = ctx->fix_list;
     a.fix_cap = ctx->fix_cap;
     // a partial launch (ctx->part: hybrid arithmetic, pipelined row bands) marches the tiles of a caller-made list; the
@@ -1412,7 +1432,31 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
             else hipLaunchKernelGGL(march_tile_guard_kernel<false>, grid, block, 0, ctx->stream, a);
 #endif
         } else if (want_diff) {
+#if !BHR_MARCH_STRICT
+            // BHR_MIP_LDS=1: the coarse mip levels through LDS where any of them fits 48 KB (see the kernel)
+            size_t staged_bytes = 0;
+            if (const char *e = getenv("BHR_MIP_LDS")) {
+                if (atoi(e) != 0 && !part.active && bt == 256) {
+                    const int last = 3;                                     // int(clamp(lod, 0, 3)): the coarsest level ever sampled
+                    for (int l = last; l >= 1; --l) {
+                        if (a.sc.mip_h[last] <= 0 || a.sc.mip_w[last] <= 0) break;                  // a texture too small to have it
+                        const size_t bytes = ((size_t)a.sc.mip_off[last] + (size_t)a.sc.mip_h[last] * a.sc.mip_w[last] - (size_t)a.sc.mip_off[l]) * sizeof(float4);
+                        if (bytes > 48 * 1024) break;
+                        a.mip_lds_from = l;
+                        staged_bytes = bytes;
+                    }
+                }
+            }
+            if (a.mip_lds_from >= 0) {
+                ctx->mip_lds_from = a.mip_lds_from;
+                hipLaunchKernelGGL(march_tile_mipstaged_kernel, grid, block, staged_bytes, ctx->stream, a);
+            } else {
+                ctx->mip_lds_from = -1;
+                hipLaunchKernelGGL((march_tile_kernel<true, 0>), grid, block, 0, ctx->stream, a);
+            }
+#else
             hipLaunchKernelGGL((march_tile_kernel<true, 0>), grid, block, 0, ctx->stream, a);
+#endif
         } else {
             hipLaunchKernelGGL((march_tile_kernel<false, 0>), grid, block, 0, ctx->stream, a);
         }

@@ -409,6 +409,10 @@ class HipRenderer:
         _lib.check(self._lib.bhr_lens_flare_sums(self._ctx, out))
         return np.array(out[:], dtype=np.float64)
 
+    def mip_lds_level(self) -> int:
+        """First mip level the last anti-aliased fast march staged in LDS (environment BHR_MIP_LDS=1), -1 if none."""
+        return int(self._lib.bhr_mip_lds_level(self._ctx))
+
     def row_costs(self, cam_pos, fov: float, split: bool = False):
         """Ray-steps per band of 8 rows for this view (one march with BHR_ROW_COSTS, no bloom).  split=True: the pair
         (steps taken by the fast arithmetic, steps taken by the strict arithmetic) -- a hybrid frame has both."""
