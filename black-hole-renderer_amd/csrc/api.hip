@@ -211,15 +211,22 @@ int32_t bhr_fail(int32_t code, const char *fmt, ...) {
 
 int32_t bhr_aux_fork(bhr_ctx *ctx) {
     const int k = ctx->active_slot >= 0 && ctx->active_slot < BHR_MAX_FRAME_SLOTS ? ctx->active_slot : 0;
-    if (!ctx->aux_stream) {
+    if (!ctx->aux_streams[0]) {
         int lo = 0, hi = 0;
         BHR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least priority
-        BHR_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, lo));
+        // BHR_AUX_STREAMS="<priority>,<per slot>" (experiments of DESIGN 7): -1 least / 0 normal / 1 highest; 0 one stream
+        // for both frame slots / 1 one each
+        int prio_sel = 0, per_slot = 1;
+        if (const char *e = getenv("BHR_AUX_STREAMS")) (void)sscanf(e, "%d,%d", &prio_sel, &per_slot);
+        ctx->aux_per_slot = per_slot != 0;
+        const int prio = prio_sel == 0 ? 0 : (prio_sel > 0 ? hi : lo);
         for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q) {
+            BHR_HIP(hipStreamCreateWithPriority(&ctx->aux_streams[q], hipStreamNonBlocking, prio));
             BHR_HIP(hipEventCreateWithFlags(&ctx->aux_fork[q], hipEventDisableTiming));
             BHR_HIP(hipEventCreateWithFlags(&ctx->aux_done[q], hipEventDisableTiming));
         }
     }
+    ctx->aux_stream = ctx->aux_streams[ctx->aux_per_slot ? k : 0];
     BHR_HIP(hipEventRecord(ctx->aux_fork[k], ctx->stream));
     BHR_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork[k], 0));
     return BHR_OK;
@@ -368,7 +375,8 @@ void bhr_destroy(bhr_ctx *ctx) {
     bhr_population_free(ctx);
     bhr_hybrid_free(ctx);
     bhr_pipe_free(ctx);
-    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q)
+        if (ctx->aux_streams[q]) { (void)hipStreamSynchronize(ctx->aux_streams[q]); (void)hipStreamDestroy(ctx->aux_streams[q]); }
     for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q) {
         if (ctx->aux_fork[q]) (void)hipEventDestroy(ctx->aux_fork[q]);
         if (ctx->aux_done[q]) (void)hipEventDestroy(ctx->aux_done[q]);

@@ -204,7 +204,9 @@ struct bhr_ctx {
     bhr_march_part part;       // partial launch in progress (inactive: whole block)
     // second march stream (lowest priority): the other half of a split march -- the fast tiles of a hybrid march, the middle
     // rows of a pipelined row block -- runs beside the first half instead of behind its ragged end (bhr_aux_fork / _join)
-    hipStream_t aux_stream;
+    hipStream_t aux_stream;    // the active slot's second march stream (set by bhr_aux_fork)
+    hipStream_t aux_streams[BHR_MAX_FRAME_SLOTS];
+    int32_t aux_per_slot;
     hipEvent_t aux_fork[BHR_MAX_FRAME_SLOTS], aux_done[BHR_MAX_FRAME_SLOTS];
     void *hybrid;              // hybrid.hip: tile classification cache
     unsigned int *fix_count;   // fix list of the hybrid march being launched (owned by hybrid.hip, per frame slot)
