@@ -49,13 +49,22 @@ void activate_slot(bhr_ctx *ctx, int k) {
     ctx->active_slot = k;
 }
 
+// experiment (BHR_STREAM_PAD="a,b,c"): idle streams created in front of frame slot 0's, slot 1's and the second march
+// streams -- HIP hands streams to its hardware queues in creation order, and which queues the frame slots land on decides
+// how their launches interleave
+static void pad_streams(int which) {
+    int n[3] = {0, 0, 0};
+    if (const char *e = getenv("BHR_STREAM_PAD")) (void)sscanf(e, "%d,%d,%d", &n[0], &n[1], &n[2]);
+    for (int k = 0; k < n[which] && k < 8; ++k) { hipStream_t s; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }   // leaked on purpose
+}
+
 int32_t alloc_slot(bhr_ctx *ctx, int k) {
     bhr_frame_slot &f = ctx->slots[k];
     if (f.allocated) return BHR_OK;
     const size_t W = ctx->cfg.width, rows = ctx->rows, R = ctx->bloom_R, px3 = rows * W * 3;
     if (!f.stream) {
         if (k == 0 && ctx->n_slots == 1) f.stream = ctx->scene_stream;
-        else BHR_HIP(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+        else { pad_streams(k == 0 ? 0 : 1); BHR_HIP(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking)); }
     }
     if (!f.done) BHR_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
     if (!f.march_done) BHR_HIP(hipEventCreateWithFlags(&f.march_done, hipEventDisableTiming));
@@ -220,6 +229,7 @@ int32_t bhr_aux_fork(bhr_ctx *ctx) {
         if (const char *e = getenv("BHR_AUX_STREAMS")) (void)sscanf(e, "%d,%d", &prio_sel, &per_slot);
         ctx->aux_per_slot = per_slot != 0;
         const int prio = prio_sel == 0 ? 0 : (prio_sel > 0 ? hi : lo);
+        pad_streams(2);
         for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q) {
             BHR_HIP(hipStreamCreateWithPriority(&ctx->aux_streams[q], hipStreamNonBlocking, prio));
             BHR_HIP(hipEventCreateWithFlags(&ctx->aux_fork[q], hipEventDisableTiming));
