@@ -11,10 +11,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(tmp, tag, n_frames, size, frame_slots, png_level, pairs_on_host):
+def _run(tmp, tag, n_frames, size, frame_slots, png_level, pairs_on_host, math=None):
     from bhr_amd import drivers
     w, h = size
-    r, _, _, _ = drivers.make_renderer(w, h, [6, 0, 0.5], 90, n_stars=600, tex_w=512, tex_h=256, frame_slots=frame_slots)
+    r, _, _, _ = drivers.make_renderer(w, h, [6, 0, 0.5], 90, n_stars=600, tex_w=512, tex_h=256, frame_slots=frame_slots, math=math)
     assert r.frame_slots == frame_slots
     if pairs_on_host:
         r.accumulate_entity_layer = functools.partial(r.accumulate_entity_layer, pairs_on_host=True)
@@ -25,12 +25,15 @@ def _run(tmp, tag, n_frames, size, frame_slots, png_level, pairs_on_host):
     return drivers._frames_dir(out)
 
 
-@pytest.mark.parametrize("size,n_frames", [((1920, 1080), 40), ((320, 180), 150)])
-def test_overlapped_video_loop_writes_the_frames_of_the_serial_loop(tmp_path, size, n_frames, hip_lib):
+@pytest.mark.parametrize("size,n_frames,math", [((1920, 1080), 40, None), ((320, 180), 150, None),
+                                                 ((1920, 1080), 40, "hybrid"), ((320, 180), 150, "hybrid")])
+def test_overlapped_video_loop_writes_the_frames_of_the_serial_loop(tmp_path, size, n_frames, math, hip_lib):
+    """math="hybrid": two tile lists per frame on two streams, per-slot cached lists, the second march streams -- the frames
+    of two slots in flight must still be the frames of one"""
     from PIL import Image
     from bhr_amd.output import DEVICE
-    serial = _run(str(tmp_path), "serial", n_frames, size, frame_slots=1, png_level=0, pairs_on_host=True)
-    overlapped = _run(str(tmp_path), "overlapped", n_frames, size, frame_slots=2, png_level=DEVICE, pairs_on_host=False)
+    serial = _run(str(tmp_path), "serial", n_frames, size, frame_slots=1, png_level=0, pairs_on_host=True, math=math)
+    overlapped = _run(str(tmp_path), "overlapped", n_frames, size, frame_slots=2, png_level=DEVICE, pairs_on_host=False, math=math)
     differing = []
     for f in range(n_frames):
         a = np.asarray(Image.open(os.path.join(serial, f"frame_{f:04d}.png")).convert("RGB"))
