@@ -1017,9 +1017,9 @@ __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
 #if !BHR_MARCH_STRICT
 // BASELINE.json's north star asks for "mipmap levels staged through LDS".  Opt-in (BHR_MIP_LDS=1, fast arithmetic,
 // anti-aliased views): every block copies the coarse levels of the packed mip stack -- as many of levels 3, 2, 1 as fit
-// 48 KB -- into LDS before it marches, and _sample_disk_mip reads those levels from there.  Not the default, by
+// 44 KB -- into LDS before it marches, and _sample_disk_mip reads those levels from there.  Not the default, by
 // measurement: the texture gathers are cache resident (FETCH_SIZE 0.36x the algorithmic bytes) and the kernel
-// is issue bound, while 48 KB of LDS leave two blocks per CU; and the BASELINE textures' level 3 (4.8 MB at 4k) does not
+// is issue bound, while 40 KB of LDS beside the parking slots leave two blocks per CU; and the BASELINE textures' level 3 (4.8 MB at 4k) does not
 // fit any LDS -- the launcher falls back to the plain kernel when nothing fits.
 __global__ __launch_bounds__(256) void march_tile_mipstaged_kernel(BhrMarchArgs a) {
     const int from = a.mip_lds_from;
@@ -1433,7 +1433,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
 #endif
         } else if (want_diff) {
 #if !BHR_MARCH_STRICT
-            // BHR_MIP_LDS=1: the coarse mip levels through LDS where any of them fits 48 KB (see the kernel)
+            // BHR_MIP_LDS=1: the coarse mip levels through LDS where any of them fits 44 KB (see the kernel)
             size_t staged_bytes = 0;
             if (const char *e = getenv("BHR_MIP_LDS")) {
                 if (atoi(e) != 0 && !part.active && bt == 256) {
@@ -1441,7 +1441,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
                     for (int l = last; l >= 1; --l) {
                         if (a.sc.mip_h[last] <= 0 || a.sc.mip_w[last] <= 0) break;                  // a texture too small to have it
                         const size_t bytes = ((size_t)a.sc.mip_off[last] + (size_t)a.sc.mip_h[last] * a.sc.mip_w[last] - (size_t)a.sc.mip_off[l]) * sizeof(float4);
-                        if (bytes > 48 * 1024) break;
+                        if (bytes > 44 * 1024) break;                       // 64 KB per block less the 18 KB of parking slots
                         a.mip_lds_from = l;
                         staged_bytes = bytes;
                     }

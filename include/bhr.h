@@ -265,7 +265,7 @@ BHR_API int32_t bhr_timing_dump(bhr_ctx *ctx, float *out, int32_t n);
  * The step count of a ray depends on the camera, the step size and the escape radius only -- not on the
  * textures -- so a small probe frame gives the cost profile of a large one (multigpu.balanced_row_blocks). */
 /* BHR_MIP_LDS=1 (environment): anti-aliased frames of the fast arithmetic stage the coarse levels of the disk texture's mip
- * stack in LDS -- as many of levels 3, 2, 1 as fit 48 KB -- and sample them from there (BASELINE.json's "mipmap levels staged
+ * stack in LDS -- as many of levels 3, 2, 1 as fit 44 KB -- and sample them from there (BASELINE.json's "mipmap levels staged
  * through LDS"; not the default: DESIGN.md section 4).  Returns the first staged level of the last such march, -1 if it staged
  * none (switch off, another arithmetic, or a texture whose level 3 alone exceeds the budget). */
 BHR_API int32_t bhr_mip_lds_level(bhr_ctx *ctx);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BHR_MIP_LDS (coarse mip levels of the disk texture staged in LDS, csrc/march.hip: march_tile_mipstaged_kernel) against
-the plain fast anti-aliased march at 4k, textures small enough for their levels 2-3 / 3 to fit 48 KB.
+the plain fast anti-aliased march at 4k, textures small enough for their levels 2-3 / 3 to fit 44 KB.
 usage: python tools/exp_mip_lds.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
