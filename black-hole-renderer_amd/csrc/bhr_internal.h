@@ -34,7 +34,9 @@
 
 // hybrid march: guard bands around the algorithm's switches; a lane inside one is re-marched strict (march.hip: march_tile_hybrid)
 #ifndef BHR_LOD_GUARD
-#define BHR_LOD_GUARD 2e-3f         // |lod - level boundary| (the fast differentials are good to ~1e-5 in lod away from the ring)
+#define BHR_LOD_GUARD 1e-2f         // |lod - level boundary|: the fast differentials are good to ~1e-5 in lod at the BASELINE views, but a camera
+                                    // 15-50 r_s away behind a long lens carries them through hundreds of steps -- fuzzed 512x320 views flipped
+                                    // levels with 2e-3 (3 of 6 gone at 5e-3, all at 1e-2; no measurable cost at 4k: tools/dbg_flipviews.sh)
 #endif
 #ifndef BHR_R2_GUARD
 #define BHR_R2_GUARD 4e-5f          // |r^2 - r_term^2| / r_term^2 of a plane-crossing step (fast positions are good to ~1e-6 relative)

@@ -2,7 +2,7 @@
 recorded in DESIGN 2): N random views as tests/test_gpu_fuzz.py draws them -- cameras from 1.15 to 60 r_s, any tilt,
 three step sizes, both AA modes -- at 192x128 (384 tiles).  Per view: per-channel RMSE of both layers, pixels that differ
 by more than 0.05 (a ray that hits the disk under one arithmetic and not the other), ray-step totals, share of strict tiles.
-Usage: python tools/fuzz_hybrid.py [n_cases] [seed] [--out file.json]"""
+Usage: python tools/fuzz_hybrid.py [n_cases] [seed] [--out file.json] [--size W H]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,11 +10,16 @@ import numpy as np
 from bhr_amd import HipRenderer, _lib, scenes
 from test_gpu_fuzz import _cases
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+_skip = set()
+for _f, _n in (("--out", 1), ("--size", 2)):
+    if _f in sys.argv:
+        _i = sys.argv.index(_f)
+        _skip.update(range(_i, _i + _n + 1))
+args = [a for k, a in enumerate(sys.argv) if k > 0 and k not in _skip]
 n = int(args[0]) if len(args) > 0 else 1000
 seed = int(args[1]) if len(args) > 1 else 11
 out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "gpurun_out", "fuzz_hybrid.json")
-w, h = 192, 128
+w, h = (int(sys.argv[sys.argv.index("--size") + 1]), int(sys.argv[sys.argv.index("--size") + 2])) if "--size" in sys.argv else (192, 128)
 sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
 rows, bad = [], []
 for k, c in enumerate(_cases(n, seed)):
