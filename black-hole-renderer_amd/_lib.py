@@ -24,7 +24,7 @@ SYMBOLS = (
     "bhr_set_skybox", "bhr_skybox_add_glow", "bhr_skybox_build", "bhr_get_skybox", "bhr_set_disk_texture", "bhr_get_disk_texture", "bhr_get_disk_mip", "bhr_num_mip_levels",
     "bhr_bg_init", "bhr_generate_background", "bhr_set_entity_staging", "bhr_set_comp", "bhr_read_comp",
     "bhr_fill_comp_slice", "bhr_set_compose_stats", "bhr_compose_texture", "bhr_eval_noise", "bhr_render",
-    "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_get_row_costs_split", "bhr_mip_lds_level", "bhr_hybrid_info", "bhr_timing_reset", "bhr_timing_dump", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_group_render_subset", "bhr_read_gathered", "bhr_read_gathered_u8", "bhr_tile_export", "bhr_tile_connect", "bhr_tile_render", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities", "bhr_accumulate_population",
+    "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_get_row_costs_split", "bhr_mip_lds_level", "bhr_hybrid_info", "bhr_hybrid_repairs", "bhr_timing_reset", "bhr_timing_dump", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_group_render_subset", "bhr_read_gathered", "bhr_read_gathered_u8", "bhr_tile_export", "bhr_tile_connect", "bhr_tile_render", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities", "bhr_accumulate_population",
     "bhr_stats_prepare", "bhr_stats_select", "bhr_stats_row_statistics",
     "bhr_png_bound", "bhr_png_encode", "bhr_png_write", "bhr_png_device_bound", "bhr_png_device_max_width", "bhr_png_encode_device", "bhr_png_device_menu",
     "bhr_sink_create", "bhr_sink_submit", "bhr_sink_drain",
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
     lib.bhr_timing_dump.argtypes = [P, F, I32]
     lib.bhr_hybrid_info.argtypes = [P, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     lib.bhr_get_row_costs.argtypes = [P, C.POINTER(C.c_uint64), I32]
+    lib.bhr_hybrid_repairs.argtypes = [P, C.POINTER(I32)]
     lib.bhr_mip_lds_level.argtypes = [P]
     lib.bhr_mip_lds_level.restype = I32
     lib.bhr_get_row_costs_split.argtypes = [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), I32]

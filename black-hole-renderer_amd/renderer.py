@@ -453,7 +453,10 @@ class HipRenderer:
         """Tile split and band of the last math="hybrid" march (bhr_hybrid_info)."""
         t, b = (C.c_int32 * 2)(), (C.c_double * 2)()
         _lib.check(self._lib.bhr_hybrid_info(self._ctx, t, b))
-        return {"strict_tiles": int(t[0]), "tiles": int(t[1]), "band_below": float(b[0]), "band_above": float(b[1])}
+        rep = (C.c_int32 * 2)()
+        _lib.check(self._lib.bhr_hybrid_repairs(self._ctx, rep))
+        return {"strict_tiles": int(t[0]), "tiles": int(t[1]), "band_below": float(b[0]), "band_above": float(b[1]),
+                "repaired_pixels": int(rep[0]), "repair_capacity": int(rep[1])}
 
     def timing_reset(self) -> None:
         _lib.check(self._lib.bhr_timing_reset(self._ctx))

@@ -251,6 +251,10 @@ BHR_API int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out);
 /* Last BHR_MATH_HYBRID march of this context: out_tiles = {tiles marched strict, tiles of the row block},
  * out_band = {lo, hi}: the strict band [b_c - lo, b_c + hi] of impact parameters, in r_s. */
 BHR_API int32_t bhr_hybrid_info(bhr_ctx *ctx, int32_t out_tiles[2], double out_band[2]);
+/* Guards of the last BHR_MATH_HYBRID frame: out = {pixels its fast list handed over to the strict fix kernel, capacity of that
+ * list}.  The count runs past the capacity -- pixels beyond it keep their fast value -- so out[0] > out[1] says that a view
+ * needs a larger list than an eighth of the block's pixels.  {0, 0}: the frame ran without guards.  Synchronises. */
+BHR_API int32_t bhr_hybrid_repairs(bhr_ctx *ctx, int32_t out[2]);
 /* Device self-test of the strict march's hand-written exact sqrt / divide / divide-by-6 against the
  * compiler's IEEE sequences: out[0..2] = mismatches (sqrt over every f32 in [2^-80, 2^80); 1/x over
  * the same range plus a/b over 2^30 random pairs; x/6 over the same range), out[3] = comparisons made. */

@@ -258,3 +258,21 @@ def test_edge_on_camera_marches_the_in_plane_rays_strict(cam, tilt, hip_lib):
         d = np.abs(a - b).max(axis=2)
         e = np.sqrt(np.mean((a.astype(np.float64) - b) ** 2, axis=(0, 1)))
         assert (e <= 3e-5).all() and int((d > 1e-2).sum()) == 0, (e, int((d > 1e-2).sum()), info)
+
+
+def test_hybrid_repairs_are_counted_and_fit_their_list(hip_lib):
+    """bhr_hybrid_repairs: a tilted anti-aliased view hands a small share of its pixels to the strict fix kernel, well inside the
+    list (an eighth of the pixels); the default view runs without guards."""
+    from bhr_amd import HipRenderer, scenes
+    sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
+    kw = dict(step_size=0.1, r_max=10.0, r_disk_inner=2.0, r_disk_outer=15.0)
+    r = HipRenderer(960, 544, sky, tex, math="hybrid", disk_tilt=25.0, anti_alias="lod_radius", aa_strength=1.5, **kw)
+    r.render_async([6.0, 0.0, 0.5], 90.0, skip_bloom=True)
+    info = r.hybrid_info()
+    r.close()
+    assert 0 < info["repaired_pixels"] <= 0.03 * 960 * 544 and info["repair_capacity"] == 960 * 544 // 8, info
+    r = HipRenderer(960, 544, sky, tex, math="hybrid", disk_tilt=0.0, **kw)
+    r.render_async([6.0, 0.0, 0.5], 90.0, skip_bloom=True)
+    info = r.hybrid_info()
+    r.close()
+    assert info["repaired_pixels"] == 0 and info["repair_capacity"] == 0, info

@@ -36,7 +36,8 @@ for k, c in enumerate(_cases(n, seed)):
     flips = int(sum((np.abs(lay["hybrid"][j] - lay["strict"][j]).max(axis=2) > 0.05).sum() for j in (0, 1)))
     dstep = abs(steps["hybrid"] - steps["strict"]) / max(steps["strict"], 1)
     row = dict(k=k, r_cam=float(np.linalg.norm(c["cam"])), rmse=e, flips=flips, step_rel=dstep,
-               strict_share=info["strict_tiles"] / max(info["tiles"], 1), finite=bool(np.isfinite(lay["hybrid"][0]).all() and np.isfinite(lay["hybrid"][1]).all()))
+               strict_share=info["strict_tiles"] / max(info["tiles"], 1), repaired_share=info["repaired_pixels"] / (w * h),
+               repair_overflow=bool(info["repaired_pixels"] > info["repair_capacity"] > 0), finite=bool(np.isfinite(lay["hybrid"][0]).all() and np.isfinite(lay["hybrid"][1]).all()))
     rows.append(row)
     if e > 6e-5 or flips or dstep > 2e-4 or not row["finite"]:
         bad.append(dict(row, case={kk: (vv if not isinstance(vv, dict) else {a: (float(b) if not isinstance(b, str) else b) for a, b in vv.items()}) for kk, vv in c.items() if kk != "cam"},
@@ -46,7 +47,8 @@ for k, c in enumerate(_cases(n, seed)):
 rm = np.array([x["rmse"] for x in rows])
 summary = dict(n=n, seed=seed, size=[w, h], outside=len(bad), worst_rmse=float(rm.max()), median_rmse=float(np.median(rm)),
                q99_rmse=float(np.quantile(rm, 0.99)), over_3e5=int((rm > 3e-5).sum()), flips=int(sum(x["flips"] for x in rows)),
-               mean_strict_share=float(np.mean([x["strict_share"] for x in rows])), bounds="RMSE <= 6e-5, no pixel beyond 0.05, step totals within 2e-4")
+               mean_strict_share=float(np.mean([x["strict_share"] for x in rows])), max_repaired_share=float(max(x["repaired_share"] for x in rows)),
+               repair_overflows=int(sum(x["repair_overflow"] for x in rows)), bounds="RMSE <= 6e-5, no pixel beyond 0.05, step totals within 2e-4")
 print(json.dumps(summary))
 os.makedirs(os.path.dirname(out), exist_ok=True)
 json.dump(dict(summary=summary, bad=bad[:50]), open(out, "w"), indent=1)
