@@ -52,6 +52,7 @@ struct Hybrid {
     double key[12];
     int32_t n_strict, valid;
     double lo, hi;                 // band below / above b_c (BHR_HYBRID_BAND="lo,hi")
+    double eff_lo, eff_hi;         // ... as the last march used it (widened with the step size beyond 0.1)
     int32_t last_fix_slot;         // frame slot whose fix list the last march used, -1: it ran without guards
 };
 
@@ -207,8 +208,8 @@ extern "C" int32_t bhr_hybrid_info(bhr_ctx *ctx, int32_t out_tiles[2], double ou
     if (!h || !h->valid) return bhr_fail(BHR_ERR_STATE, "bhr_hybrid_info: no hybrid march has run on this context");
     out_tiles[0] = h->n_strict;
     out_tiles[1] = (int32_t)h->strict.size();
-    out_band[0] = h->lo;
-    out_band[1] = h->hi;
+    out_band[0] = h->eff_lo;
+    out_band[1] = h->eff_hi;
     return BHR_OK;
 }
 
@@ -257,9 +258,15 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     const int id = base.active ? base.id : 0;
     if (id < 0 || id >= HYBRID_LISTS || !base_list) return bhr_fail(BHR_ERR_INVALID, "hybrid march: bad base list %d", id);
     double key[12];
-    view_key(cam, h->lo, h->hi, (double)ctx->cfg.disk_tilt_deg, key);
+    // the band was certified at step sizes up to 0.1; a coarser march amplifies more per step around the ring (a 0.3 march
+    // lost a faint crossing at b_c + 0.59 that the binary64 evaluation keeps): the band widens with the step
+    const double widen = ctx->cfg.step_size > 0.1f ? (double)ctx->cfg.step_size / 0.1 : 1.0;
+    const double lo = h->lo * widen, hi = h->hi * widen;
+    h->eff_lo = lo;
+    h->eff_hi = hi;
+    view_key(cam, lo, hi, (double)ctx->cfg.disk_tilt_deg, key);
     if (!h->valid || !same_view(h->key, key)) {
-        classify(ctx, cam, h->lo, h->hi, h->strict);
+        classify(ctx, cam, lo, hi, h->strict);
         int n = 0;
         for (int k = 0; k < ctx->tile_order_n; ++k) n += h->strict[(size_t)k];
         h->n_strict = n;

@@ -99,8 +99,8 @@ def test_telephoto_views_hybrid_within_the_f32_noise_of_the_march(k, n, seed, or
     _, d64 = ora.march(c["cam"], c["fov"], frame=c["frame"])
     d64 = d64.transpose(1, 0, 2)
     # up to two pixels of the 24 576 may sit on the other side of a faint disk-edge decision (none by more than 0.05: view
-    # 1368 has one, 0.02 of a crossing at the inner edge that the fast arithmetic does not register -- nor does the oracle's own
-    # -ffast-math build of the reference's statements; its binary64 build sides with strict --, which alone is 1.3e-4 of
+    # 1368 had one before the band widened with the step size -- 0.02 of a crossing at the inner edge that the fast arithmetic
+    # did not register, nor does the oracle's own -ffast-math build; its binary64 build sides with strict --, which alone is 1.3e-4 of
     # RMSE at this frame size): the bound applies to the frame without its two worst pixels
     worst2 = np.argsort(np.abs(lay["hybrid"] - lay["strict"]).max(axis=2).ravel())[-2:]
 
