@@ -141,3 +141,22 @@ def test_random_view_hybrid_row_blocks_equal_one_context(k, hip_lib):
     assert sum(t.counters()["ray_steps"] for t in tiles) == steps
     for t in tiles:
         t.close()
+
+
+@pytest.mark.parametrize("k", range(1, 24, 4))
+def test_random_view_row_costs_and_balanced_blocks(k, hip_lib):
+    """The cost probes behind make_tiles on six of the fuzzed views, both arithmetics: profiles are finite and positive where
+    the frame has rays, the hybrid split sums to the frame's step total, and the balanced blocks tile the frame on multiples
+    of 8 rows."""
+    from bhr_amd import multigpu
+    c = _cases()[k]
+    kw = {q: c["kw"][q] for q in ("step_size", "r_max", "r_disk_inner", "r_disk_outer", "disk_tilt")}
+    W, H = 1280, 720
+    for math in (None, "hybrid"):
+        per_row, band = multigpu.probe_row_costs(W, H, c["cam"], c["fov"], math=math, **kw)
+        assert per_row.shape == (H,) and np.isfinite(per_row).all() and (per_row >= 0).all() and per_row.sum() > 0, (k, math)
+        blocks = multigpu.balanced_row_blocks(H, 5, per_row, band, fixed_cost_per_row=0.1 * float(per_row.mean()))
+        assert blocks[0][0] == 0 and blocks[-1][1] == H and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        assert all(r0 % 8 == 0 and r1 > r0 for r0, r1 in blocks), blocks
+        cost = np.array([per_row[r0:r1].sum() for r0, r1 in blocks])
+        assert cost.max() <= 2.0 * cost.mean() + per_row.max() * 8, (k, math, blocks, cost)      # no block left with the lot
