@@ -184,6 +184,13 @@ class TileLink:
             raise ValueError(f"exchange returned {len(everyone)} records for {world} ranks")
         if self._shm is None:
             self._shm = shared_memory.SharedMemory(name=shm_name)
+            # Python < 3.13 registers ATTACHED segments with this process's resource tracker too, which then tries to unlink
+            # rank 0's segment at exit and warns when it is already gone: the segment is rank 0's to remove
+            try:
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self._shm._name, "shared_memory")
+            except Exception:
+                pass
         arr = (_lib.TileHandles * world)(*[_lib.TileHandles.from_buffer_copy(b) for b in everyone])
         self._words = (C.c_uint64 * (world * _lib.TILE_SHM_WORDS)).from_buffer(self._shm.buf)
         _lib.check(self._lib.bhr_tile_connect(renderer._ctx, rank, world, arr, self._words))
