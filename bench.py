@@ -138,12 +138,12 @@ def tile_leg(wl, n, frames, math=None, warmup=3):
     try:
         t_spin = time.perf_counter()                     # clocks back up after the tiles' scene set-up (un-timed)
         while (time.perf_counter() - t_spin) < 0.3:
-            multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer")
+            multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer_u8")
         for _ in range(max(warmup, 1)):
-            multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer")
+            multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer_u8")
         t0 = time.perf_counter()
         for _ in range(frames):
-            multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer")   # synchronises every tile's stream
+            multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer_u8")   # synchronises every tile's stream
         el = time.perf_counter() - t0
         cs = [t.counters() for t in tiles]
         steps = sum(c["ray_steps"] for c in cs)
@@ -153,7 +153,7 @@ def tile_leg(wl, n, frames, math=None, warmup=3):
                 "workload": f"{wl['width']}x{wl['height']} default scene, step_size {wl['step_size']}, one frame in {n} row blocks",
                 "row_blocks": [list(b) for b in blocks],
                 "tile_ms": {"march": [round(c["march_ms"], 3) for c in cs], "frame": [round(c["frame_ms"], 3) for c in cs]},
-                "exchange": "bloom halo rows + final gather onto device 0 with hipMemcpyPeerAsync, no collective",
+                "exchange": "bloom halo rows + gather of the quantised u8 rows (what save_image writes) onto device 0 with hipMemcpyPeerAsync, no collective",
                 "driven_by": "rank 0 drives all devices in one process (bhr_group_render); the other ranks wait at a host barrier",
                 "scene": note}
     finally:
