@@ -72,7 +72,7 @@ struct BhrMarchArgs {
     float h_base, r_inner, r_outer, t_offset;
     float tilt_rad, tan_t, sin_t, cos_t;
     float aa_strength;
-    float max_affine;
+    float max_affine, max_affine_u;   // max_affine_u = max_affine / h_base (fast build)
     int32_t max_iter;
     int32_t width, height;   // full image
     int32_t row0, rows;      // this context's row block

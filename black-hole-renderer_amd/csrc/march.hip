@@ -51,6 +51,7 @@
 #ifndef BHR_WAVE_STAMPS_BUILD
 #define BHR_WAVE_STAMPS_BUILD 0
 #endif
+
 #if BHR_MARCH_STRICT && BHR_MARCH_ILP
 // third compilation: the strict source scheduled with -mllvm -amdgpu-sched-strategy=max-ilp.  Its two texture kernels
 // are launched (march_tile_plain_ilp, march_tile_aa_ilp, each with its own occupancy target): the plain one gains 4 %
@@ -801,12 +802,14 @@ struct Ray {
     // updated in place after its last use; the state is committed unconditionally (a terminated lane leaves
     // the loop, an escaped ray reads (du, dw) back as new_dir).
     __device__ __forceinline__ bool step(const BhrMarchArgs &a) {
-        // adaptive step (render.py:2858-2869) from 1/r:  q = 1/r_safe, sqrt(r_safe) = rsq(q)
+        // adaptive step (render.py:2858-2869) from 1/r with ONE transcendental:  q = 1/r_safe, far_scale = min(sqrt(r_safe), 10)
+        // = rsq(max(q, 0.01)), near_damp = 1 / (1 + 2 q^3), so far_scale near_damp = rsq(max(q, 0.01) (1 + 2 q^3)^2).  The
+        // reference's clamp to [0.2, 10] never binds: q <= 1 / 1.001 gives far_scale >= 1 and near_damp > 1/3, and the
+        // product is <= far_scale <= 10.  (Round 3: v_rsq + v_rcp, 12.7 issue cycles each inside this instruction mix.)
         float q = fminf(ir, 1.0f / (BHR_RS + 1e-3f));
-        float far_scale = fminf(q_rsq(q), 10.0f);
-        float near_damp = q_rcp(fmaf(2.0f * q, q * q, 1.0f));
-        float dt_fac = fminf(fmaxf(far_scale * near_damp, 0.2f), 10.0f);
-        float h = a.h_base * dt_fac;
+        float nd = fmaf(2.0f * q, q * q, 1.0f);
+        float dt_fac = q_rsq(fmaxf(q, 0.01f) * (nd * nd));
+        float h = a.h_base * dt_fac;       // (h_base in a vector register would save 2 issue cycles and cost the plain kernel its sixth wave: 80 -> 90 VGPRs)
         float hh = 0.5f * h;
         float h6 = h * (1.0f / 6.0f);
 
@@ -830,10 +833,12 @@ struct Ray {
         float sdw = fmaf(c4, s4w, a1w) + 2.0f * (a2w + a3w);
 
         float r2n = fmaf(nu, nu, nw * nw);
-        float aff = affine + h;
+        // the affine parameter is kept in units of h_base: one plain v_add per step instead of an FMA with a scalar operand
+        // (half rate), compared against max_affine / h_base
+        float aff = affine + dt_fac;
         // termination precedes the plane test (render.py:2916-2926); r < 1  <=>  r^2 < 1 etc.
         const bool captured = r2n < BHR_RS * BHR_RS;
-        const bool escaped = !captured && (r2n > a.r_esc2 || aff > a.max_affine);
+        const bool escaped = !captured && (r2n > a.r_esc2 || aff > a.max_affine_u);
         const bool alive = !captured && !escaped;
         float f_new = Bn * nw;
         // Discontinuity guard (read by the hybrid kernel only): a step that crosses the disk plane registers the hit only
@@ -934,7 +939,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v) {
 // GUARD (the fast list of a hybrid march, fast object only): a lane that came within a guard band of one of the
 // algorithm's switches (Shade.unsure) does not write its pixel; it appends it to the context's fix list, which
 // march_fix_kernel (strict objects) marches again with the strict Ray.
-template <bool DIFF, int SRC = 0, bool GUARD = false>
+template <bool DIFF, int SRC = 0, bool GUARD = false, bool COSTS = true>
 __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int slot) {
     const int lane = threadIdx.x & 63;
     // one 8x8 tile per wave; `slot` is its position in the launch order
@@ -958,11 +963,38 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
     // empty (the hardware form of "loop while __ballot(alive)").  Written without an inner `if` because
     // hipcc otherwise shuttles the whole ray state through v_mov at every iteration (24 moves/step).
     unsigned int flushes = 0;     // wave-uniform
+#if !BHR_MARCH_STRICT
+    // Fast build: values that are uniform over the live lanes but read behind the divergent loop (the step count, the
+    // number of shading passes) are kept in scalar registers by hipcc and copied into a vector register in EVERY
+    // iteration for the lanes that leave (v_mov from an SGPR: 4 issue cycles each).  The lane's own count in a vector
+    // register costs one plain v_add.  The shading passes inside the loop are counted only by the instantiations that
+    // fill the row-cost profile (COSTS: BHR_ROW_COSTS launches): the plain kernel sits exactly at 80 registers = 6 waves
+    // per SIMD, and one more value alive across the loop costs it a wave of occupancy.
+    int cnt = 0, passes = 0;
+    asm volatile("" : "+v"(cnt));
+    if (COSTS) asm volatile("" : "+v"(passes));
+    while (ray.done == 0) {
+        ray.step(a);
+        cnt += 1;
+        if (__ballot(ray.n_pend == 2)) {
+            ray.flush_one(a);
+            if (COSTS) passes += 1;
+        }
+    }
+    ray.step_count = cnt;
+    if (COSTS) {   // the lanes that were alive at the wave's last pass have seen them all
+        int m = passes;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, BHR_WAVE));
+        flushes = (unsigned int)m;
+    }
+#else
     while (ray.done == 0) {
         ray.step(a);
         // some live lane has filled both its parking slots: every live lane shades its older crossing
         if (__ballot(ray.n_pend == 2)) { ray.flush_one(a); flushes += 1u; }
     }
+#endif
     if (__ballot(ray.n_pend > 0)) { ray.flush_one(a); flushes += 1u; }
     if (__ballot(ray.n_pend > 0)) { ray.flush_one(a); flushes += 1u; }
     {
@@ -1009,9 +1041,9 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
     }
 }
 
-template <bool DIFF, int SRC = 0>
+template <bool DIFF, int SRC = 0, bool COSTS = false>
 __global__ __launch_bounds__(256) void march_tile_kernel(BhrMarchArgs a) {
-    march_tile_body<DIFF, SRC>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    march_tile_body<DIFF, SRC, false, COSTS>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
 #if !BHR_MARCH_STRICT
@@ -1027,12 +1059,12 @@ __global__ __launch_bounds__(256) void march_tile_mipstaged_kernel(BhrMarchArgs 
     const float4 *src = a.sc.mips + a.sc.mip_off[from];
     for (int k = threadIdx.x; k < n; k += 256) g_mip_lds[k] = src[k];
     __syncthreads();
-    march_tile_body<true, 3>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    march_tile_body<true, 3, false, false>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
-template <bool DIFF>
+template <bool DIFF, bool COSTS = false>
 __global__ __launch_bounds__(256) void march_tile_guard_kernel(BhrMarchArgs a) {
-    march_tile_body<DIFF, 0, true>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    march_tile_body<DIFF, 0, true, COSTS>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 #endif
 
@@ -1314,6 +1346,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     // render.py:2817-2818
     a.max_iter = (int32_t)(a.r_esc * 40.0f / a.h_base);
     a.max_affine = a.r_esc * 40.0f;
+    a.max_affine_u = a.max_affine / a.h_base;      // fast build: the affine parameter in units of h_base
     a.width = c.width;
     a.height = c.height;
     a.row0 = c.row0;
@@ -1428,8 +1461,14 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
 #else
 #if !BHR_MARCH_STRICT
         } else if (part.active && part.repair == 1) {           // fast list of a hybrid march: guards + fix list
-            if (want_diff) hipLaunchKernelGGL(march_tile_guard_kernel<true>, grid, block, 0, ctx->stream, a);
-            else hipLaunchKernelGGL(march_tile_guard_kernel<false>, grid, block, 0, ctx->stream, a);
+            if (a.row_steps) {                                  // the row-cost probe: the instantiations that count shading passes
+                if (want_diff) hipLaunchKernelGGL((march_tile_guard_kernel<true, true>), grid, block, 0, ctx->stream, a);
+                else hipLaunchKernelGGL((march_tile_guard_kernel<false, true>), grid, block, 0, ctx->stream, a);
+            } else if (want_diff) hipLaunchKernelGGL((march_tile_guard_kernel<true>), grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((march_tile_guard_kernel<false>), grid, block, 0, ctx->stream, a);
+        } else if (a.row_steps) {
+            if (want_diff) hipLaunchKernelGGL((march_tile_kernel<true, 0, true>), grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((march_tile_kernel<false, 0, true>), grid, block, 0, ctx->stream, a);
 #endif
         } else if (want_diff) {
 #if !BHR_MARCH_STRICT
