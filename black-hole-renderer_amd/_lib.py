@@ -17,6 +17,7 @@ SKIP_DIFFERENTIALS, SKIP_BLOOM, PERSISTENT, FORCE_FAST, FORCE_STRICT, LENS_FLARE
 FORCE_HYBRID, GATHER_U8, GROUP_SERIAL, GROUP_PIPELINED = 256, 512, 1024, 2048
 MATH_FAST, MATH_STRICT, MATH_HYBRID = 0, 1, 2
 LAYER_FINAL, LAYER_BG, LAYER_DISK, LAYER_BLUR = 0, 1, 2, 3
+OUTPUT_F32, OUTPUT_BLUR, OUTPUT_U8 = 1, 2, 4
 
 # every symbol include/bhr.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
@@ -24,7 +25,7 @@ SYMBOLS = (
     "bhr_set_skybox", "bhr_skybox_add_glow", "bhr_skybox_build", "bhr_get_skybox", "bhr_set_disk_texture", "bhr_get_disk_texture", "bhr_get_disk_mip", "bhr_num_mip_levels",
     "bhr_bg_init", "bhr_generate_background", "bhr_set_entity_staging", "bhr_set_comp", "bhr_read_comp",
     "bhr_fill_comp_slice", "bhr_set_compose_stats", "bhr_compose_texture", "bhr_eval_noise", "bhr_render",
-    "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_get_row_costs_split", "bhr_mip_lds_level", "bhr_hybrid_info", "bhr_hybrid_repairs", "bhr_timing_reset", "bhr_timing_dump", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_group_render_subset", "bhr_read_gathered", "bhr_read_gathered_u8", "bhr_tile_export", "bhr_tile_connect", "bhr_tile_render", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities", "bhr_accumulate_population",
+    "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_set_outputs", "bhr_set_option", "bhr_debug_read", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_get_row_costs_split", "bhr_mip_lds_level", "bhr_hybrid_info", "bhr_hybrid_repairs", "bhr_timing_reset", "bhr_timing_dump", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_group_render_subset", "bhr_read_gathered", "bhr_read_gathered_u8", "bhr_tile_export", "bhr_tile_connect", "bhr_tile_render", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities", "bhr_accumulate_population",
     "bhr_stats_prepare", "bhr_stats_select", "bhr_stats_row_statistics",
     "bhr_png_bound", "bhr_png_encode", "bhr_png_write", "bhr_png_device_bound", "bhr_png_device_max_width", "bhr_png_encode_device", "bhr_png_device_menu",
     "bhr_sink_create", "bhr_sink_submit", "bhr_sink_drain",
@@ -114,6 +115,9 @@ def load() -> C.CDLL:
     lib.bhr_skybox_build.argtypes = [P, I32, I32, C.POINTER(C.c_uint8), I32, I32, PI32, PI32, I32, PI32, PI32, I32, I32, F, F, F, F, I32]
     lib.bhr_write_layer.argtypes = [P, I32, F]
     lib.bhr_bloom.argtypes = [P]
+    lib.bhr_set_outputs.argtypes = [P, C.c_uint32]
+    lib.bhr_set_option.argtypes = [P, C.c_char_p, C.c_double]
+    lib.bhr_debug_read.argtypes = [P, I32, C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
     lib.bhr_lens_flare.argtypes = [P]
     lib.bhr_lens_flare_sums.argtypes = [P, C.POINTER(C.c_double)]
     lib.bhr_read_final_u8.argtypes = [P, C.POINTER(C.c_uint8)]

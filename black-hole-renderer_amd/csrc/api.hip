@@ -36,6 +36,8 @@ void activate_slot(bhr_ctx *ctx, int k) {
     ctx->d_bg = f.d_bg;
     ctx->d_disk = f.d_disk;
     ctx->d_hblur = f.d_hblur;
+    ctx->d_pa = f.d_pa;
+    ctx->d_pb = f.d_pb;
     ctx->d_blur = f.d_blur;
     ctx->d_final = f.d_final;
     ctx->d_final_u8 = f.d_final_u8;
@@ -52,10 +54,38 @@ void activate_slot(bhr_ctx *ctx, int k) {
 // experiment (BHR_STREAM_PAD="a,b,c"): idle streams created in front of frame slot 0's, slot 1's and the second march
 // streams -- HIP hands streams to its hardware queues in creation order, and which queues the frame slots land on decides
 // how their launches interleave
-static void pad_streams(int which) {
-    int n[3] = {0, 0, 0};
-    if (const char *e = getenv("BHR_STREAM_PAD")) (void)sscanf(e, "%d,%d,%d", &n[0], &n[1], &n[2]);
-    for (int k = 0; k < n[which] && k < 8; ++k) { hipStream_t s; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }   // leaked on purpose
+static void pad_streams(const bhr_ctx *ctx, int which) {
+    for (int k = 0; k < ctx->opt.stream_pad[which] && k < 8; ++k) { hipStream_t s; (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }   // leaked on purpose
+}
+
+// the environment, once (bhr_create): nothing on the bhr_render path calls getenv
+static void read_options(bhr_options *o) {
+    memset(o, 0, sizeof(*o));
+    auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e && e[0] ? atoi(e) : dflt; };
+    o->frame_slots = num("BHR_FRAME_SLOTS", 2);
+    if (o->frame_slots < 1 || o->frame_slots > BHR_MAX_FRAME_SLOTS) o->frame_slots = 2;
+    o->bloom_split = num("BHR_BLOOM_SPLIT", -1);
+    if (o->bloom_split > 1) o->bloom_split = 1;
+    o->bloom_tiles = num("BHR_BLOOM_TILES", 0);
+    if (o->bloom_tiles < 0 || o->bloom_tiles > 8) o->bloom_tiles = 0;
+    o->hybrid_repair = num("BHR_HYBRID_REPAIR", -1);
+    if (o->hybrid_repair > 1) o->hybrid_repair = 1;
+    o->hybrid_band_set = 0;
+    if (const char *e = getenv("BHR_HYBRID_BAND")) {
+        double lo = 0, hi = 0;
+        if (sscanf(e, "%lf,%lf", &lo, &hi) == 2 && lo >= 0 && hi >= 0) { o->hybrid_band[0] = lo; o->hybrid_band[1] = hi; o->hybrid_band_set = 1; }
+    }
+    o->hybrid_streams = num("BHR_HYBRID_STREAMS", 2) == 1 ? 1 : 2;
+    o->mip_lds = num("BHR_MIP_LDS", 0) != 0;
+    { const char *e = getenv("BHR_TILE_ORDER"); o->tile_order_rows = e && e[0] == 'r'; }
+    o->tile_block = num("BHR_TILE_BLOCK", 256);
+    if (o->tile_block != 64 && o->tile_block != 128 && o->tile_block != 256) o->tile_block = 256;
+    o->group_threads = num("BHR_GROUP_THREADS", -1);
+    { const char *e = getenv("BHR_GROUP_SCHEDULE"); o->group_schedule = e && e[0] ? (e[0] == 's' ? 0 : 1) : -1; }
+    o->aux_priority = 0;
+    o->aux_per_slot = 1;
+    if (const char *e = getenv("BHR_AUX_STREAMS")) (void)sscanf(e, "%d,%d", &o->aux_priority, &o->aux_per_slot);
+    if (const char *e = getenv("BHR_STREAM_PAD")) (void)sscanf(e, "%d,%d,%d", &o->stream_pad[0], &o->stream_pad[1], &o->stream_pad[2]);
 }
 
 int32_t alloc_slot(bhr_ctx *ctx, int k) {
@@ -64,33 +94,54 @@ int32_t alloc_slot(bhr_ctx *ctx, int k) {
     const size_t W = ctx->cfg.width, rows = ctx->rows, R = ctx->bloom_R, px3 = rows * W * 3;
     if (!f.stream) {
         if (k == 0 && ctx->n_slots == 1) f.stream = ctx->scene_stream;
-        else { pad_streams(k == 0 ? 0 : 1); BHR_HIP(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking)); }
+        else { pad_streams(ctx, k == 0 ? 0 : 1); BHR_HIP(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking)); }
     }
     if (!f.done) BHR_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
     if (!f.march_done) BHR_HIP(hipEventCreateWithFlags(&f.march_done, hipEventDisableTiming));
     int32_t rc = BHR_OK;
+    (void)R;
     if ((rc = dev_alloc(&f.d_bg, px3)) || (rc = dev_alloc(&f.d_disk, px3)) || (rc = dev_alloc(&f.d_blur, px3)) ||
-        (rc = dev_alloc(&f.d_final, px3)) || (rc = dev_alloc(&f.d_final_u8, px3)) ||
-        (rc = dev_alloc(&f.d_hblur_base, 3 * (rows + 2 * R) * W + 2 * BHR_HBLUR_PAD_ROWS * W)) || (rc = dev_alloc(&f.d_queue, 1))) {
-        void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur_base, f.d_queue};   // a later retry starts clean
+        (rc = dev_alloc(&f.d_final, px3)) || (rc = dev_alloc(&f.d_final_u8, px3)) || (rc = dev_alloc(&f.d_queue, 1))) {
+        void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_queue};   // a later retry starts clean
         for (void *b : bufs)
             if (b) (void)hipFree(b);
-        f.d_bg = f.d_disk = f.d_blur = f.d_final = f.d_hblur = f.d_hblur_base = nullptr;
+        f.d_bg = f.d_disk = f.d_blur = f.d_final = nullptr;
         f.d_final_u8 = nullptr;
         f.d_queue = nullptr;
         return rc;
     }
-    // the halo rows of the H-blur buffer outside the image stay zero for the life of the context
-    f.d_hblur = f.d_hblur_base + BHR_HBLUR_PAD_ROWS * W;
-    BHR_HIP(hipMemsetAsync(f.d_hblur_base, 0, (3 * (rows + 2 * R) * W + 2 * BHR_HBLUR_PAD_ROWS * W) * sizeof(float), ctx->scene_stream));
-    BHR_HIP(hipStreamSynchronize(ctx->scene_stream));
     f.allocated = 1;
+    return BHR_OK;
+}
+
+// The bloom intermediates of slot k, on first use of either post-pass: the planar f32 H-blur planes of the exact kernels, or
+// the packed f16 operands of the split kernels (bloom.hip).  Zero filled: halo rows outside the image stay zero for the
+// life of the context, and so do the padding groups of the packed layouts.
+int32_t ensure_bloom_buffers(bhr_ctx *ctx, int k, bool split) {
+    bhr_frame_slot &f = ctx->slots[k];
+    const size_t W = ctx->cfg.width, rows = ctx->rows, R = ctx->bloom_R;
+    if (split) {
+        if (f.d_pa && f.d_pb) return BHR_OK;
+        bhr_split_geom g;
+        bhr_split_geometry(ctx, &g);
+        BHR_HIP(hipMalloc(&f.d_pa, g.pa_halfs * 2));
+        BHR_HIP(hipMalloc(&f.d_pb, g.pb_halfs * 2));
+        BHR_HIP(hipMemsetAsync(f.d_pa, 0, g.pa_halfs * 2, ctx->scene_stream));
+        BHR_HIP(hipMemsetAsync(f.d_pb, 0, g.pb_halfs * 2, ctx->scene_stream));
+    } else {
+        if (f.d_hblur_base) return BHR_OK;
+        const size_t n = 3 * (rows + 2 * R) * W + 2 * BHR_HBLUR_PAD_ROWS * W;
+        BHR_TRY(dev_alloc(&f.d_hblur_base, n));
+        f.d_hblur = f.d_hblur_base + BHR_HBLUR_PAD_ROWS * W;
+        BHR_HIP(hipMemsetAsync(f.d_hblur_base, 0, n * sizeof(float), ctx->scene_stream));
+    }
+    BHR_HIP(hipStreamSynchronize(ctx->scene_stream));
     return BHR_OK;
 }
 
 void free_slot(bhr_ctx *ctx, int k) {
     bhr_frame_slot &f = ctx->slots[k];
-    void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur_base, f.d_queue,
+    void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur_base, f.d_pa, f.d_pb, f.d_queue,
                     f.d_glow_hw, f.d_glow_wh, f.d_flare_c0, f.d_flare_c12, f.d_flare_sums};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -157,11 +208,70 @@ int32_t fold_cells(bhr_ctx *ctx, const unsigned long long *cells, int n, unsigne
 
 }  // namespace
 
-// FINAL (f32) -> d_final_u8 on the context's stream
-int32_t bhr_launch_quantize(bhr_ctx *ctx) {
-    const long long n = (long long)ctx->rows * ctx->cfg.width * 3;
-    hipLaunchKernelGGL(quantize_u8_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->d_final, ctx->d_final_u8, n);
-    BHR_HIP(hipGetLastError());
+// the frame's u8 rows in d_final_u8, on the context's stream: already there when its V pass stored them, else FINAL -> u8
+int32_t bhr_launch_quantize(bhr_ctx *ctx) { return bhr_ensure_outputs(ctx, BHR_OUT_U8); }
+
+int32_t bhr_ensure_outputs(bhr_ctx *ctx, uint32_t need) {
+    bhr_frame_slot &f = ctx->slots[ctx->active_slot];
+    uint32_t missing = need & ~f.have;
+    if (!missing) return BHR_OK;
+    if ((missing & BHR_OUT_U8) && ((f.have | missing) & BHR_OUT_F32)) {
+        // the f32 frame is (or is about to be) the authority -- it may carry a lens flare the V pass knows nothing of
+        if (missing & BHR_OUT_F32) BHR_TRY(bhr_ensure_outputs(ctx, BHR_OUT_F32));
+        const long long n = (long long)ctx->rows * ctx->cfg.width * 3;
+        hipLaunchKernelGGL(quantize_u8_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->d_final, ctx->d_final_u8, n);
+        BHR_HIP(hipGetLastError());
+        f.have |= BHR_OUT_U8;
+        missing &= ~(BHR_OUT_U8 | BHR_OUT_F32);
+        if (!missing) return BHR_OK;
+    }
+    // re-run the frame's V pass for what nobody asked for up front (its inputs -- bg, disk, the H-blur planes -- are still the
+    // slot's): same kernels, same bits
+    const int32_t split = ctx->bloom_split;
+    ctx->bloom_split = f.frame_split;
+    const int32_t rc = bhr_launch_bloom_v_rows(ctx, f.frame_with_bloom, 0, ctx->rows, missing, nullptr, nullptr);
+    ctx->bloom_split = split;
+    BHR_TRY(rc);
+    f.have |= missing;
+    return BHR_OK;
+}
+
+// group / tile renders and the stand-alone passes work on slot 0 whatever bhr_render left active
+int32_t bhr_activate_slot(bhr_ctx *ctx, int32_t k) {
+    if (k < 0 || k >= BHR_MAX_FRAME_SLOTS) return bhr_fail(BHR_ERR_INVALID, "frame slot %d", k);
+    BHR_TRY(alloc_slot(ctx, k));
+    activate_slot(ctx, k);
+    return BHR_OK;
+}
+
+int32_t bhr_frame_begin(bhr_ctx *ctx, uint32_t flags) {
+    int mode = ctx->cfg.math_mode;
+    if (flags & BHR_FORCE_FAST) mode = BHR_MATH_FAST;
+    if (flags & BHR_FORCE_STRICT) mode = BHR_MATH_STRICT;
+    if (flags & BHR_FORCE_HYBRID) mode = BHR_MATH_HYBRID;
+    if (mode == BHR_MATH_HYBRID && (ctx->disk_source != BHR_DISK_TEXTURE || (flags & BHR_PERSISTENT))) mode = BHR_MATH_STRICT;
+    // the frame's post-pass follows its march: exact f32 chains under strict, the split-f16 matrix-core kernels (bloom.hip)
+    // under fast and hybrid; BHR_BLOOM_SPLIT=0 / 1 forces either for every arithmetic
+    int split = ctx->opt.bloom_split >= 0 ? ctx->opt.bloom_split : (mode != BHR_MATH_STRICT ? 1 : 0);
+    if (!ctx->split_ok || (flags & BHR_SKIP_BLOOM)) split = 0;
+    ctx->bloom_split = split;
+    if (!(flags & BHR_SKIP_BLOOM)) {
+        BHR_TRY(ensure_bloom_buffers(ctx, ctx->active_slot, split != 0));
+        bhr_frame_slot &f = ctx->slots[ctx->active_slot];
+        ctx->d_hblur = f.d_hblur;
+        ctx->d_pa = f.d_pa;
+        ctx->d_pb = f.d_pb;
+    }
+    bhr_frame_slot &f = ctx->slots[ctx->active_slot];
+    f.have = 0;
+    f.frame_split = split;
+    f.frame_with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
+    return BHR_OK;
+}
+
+int32_t bhr_frame_post(bhr_ctx *ctx, int32_t with_bloom, uint32_t want) {
+    BHR_TRY(bhr_launch_bloom_v_rows(ctx, with_bloom, 0, ctx->rows, want, nullptr, nullptr));
+    ctx->slots[ctx->active_slot].have = want;
     return BHR_OK;
 }
 
@@ -225,11 +335,10 @@ int32_t bhr_aux_fork(bhr_ctx *ctx) {
         BHR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));       // lo = least priority
         // BHR_AUX_STREAMS="<priority>,<per slot>" (experiments of DESIGN 7): -1 least / 0 normal / 1 highest; 0 one stream
         // for both frame slots / 1 one each
-        int prio_sel = 0, per_slot = 1;
-        if (const char *e = getenv("BHR_AUX_STREAMS")) (void)sscanf(e, "%d,%d", &prio_sel, &per_slot);
+        const int prio_sel = ctx->opt.aux_priority, per_slot = ctx->opt.aux_per_slot;
         ctx->aux_per_slot = per_slot != 0;
         const int prio = prio_sel == 0 ? 0 : (prio_sel > 0 ? hi : lo);
-        pad_streams(2);
+        pad_streams(ctx, 2);
         for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q) {
             BHR_HIP(hipStreamCreateWithPriority(&ctx->aux_streams[q], hipStreamNonBlocking, prio));
             BHR_HIP(hipEventCreateWithFlags(&ctx->aux_fork[q], hipEventDisableTiming));
@@ -330,11 +439,10 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipSetDevice(%d) failed", cfg->device));
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipStreamCreate failed"));
     ctx->scene_stream = ctx->stream;
-    {
-        const char *e = getenv("BHR_FRAME_SLOTS");       // 2 (default): frames alternate between two slots / streams
-        ctx->n_slots = e ? atoi(e) : 2;
-        if (ctx->n_slots < 1 || ctx->n_slots > BHR_MAX_FRAME_SLOTS) ctx->n_slots = 2;
-    }
+    read_options(&ctx->opt);
+    ctx->n_slots = ctx->opt.frame_slots;                 // 2 (default): frames alternate between two slots / streams
+    ctx->split_ok = bhr_split_nt(ctx->bloom_R) <= 12;    // the split-f16 bloom's table: radius <= 176 (widths to 8849)
+    ctx->out_want = BHR_OUT_F32;
     if (hipEventCreateWithFlags(&ctx->scene_ev, hipEventDisableTiming) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipEventCreate failed"));
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipEventCreate failed"));
@@ -349,8 +457,8 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     activate_slot(ctx, 0);
     if ((rc = dev_alloc(&ctx->d_wtab, 3 * (R + 1 + 64)))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_wext, 3 * (2 * (R + 4) + 8)))) return bail(rc);
-    if ((rc = dev_alloc(&ctx->d_wsum_h, 3 * W))) return bail(rc);
-    if ((rc = dev_alloc(&ctx->d_wsum_v, 3 * H))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_wsum_h, 6 * W))) return bail(rc);
+    if ((rc = dev_alloc(&ctx->d_wsum_v, 6 * H))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_ray_steps, BHR_STEP_CELL))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_steps_ring, (size_t)BHR_TIMING_RING * BHR_STEP_CELL))) return bail(rc);
     if ((rc = dev_alloc(&ctx->d_steps_fold, BHR_TIMING_RING))) return bail(rc);
@@ -396,7 +504,7 @@ void bhr_destroy(bhr_ctx *ctx) {
     if (ctx->scene_ev) (void)hipEventDestroy(ctx->scene_ev);
     void *bufs[] = {ctx->d_skybox,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_noise_in,
-                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_wsplit, ctx->d_dv2_params,
+                    ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_w16, ctx->d_dv2_params,
                     ctx->d_flare_prog, ctx->d_tile_order, ctx->d_row_steps, ctx->d_gather};   // the flare's per-frame scratch belongs to the slots
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -593,13 +701,18 @@ namespace {
 int32_t render_on_slot(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags, int k, int ring) {
     bhr_frame_slot &f = ctx->slots[k];
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
+    BHR_TRY(bhr_frame_begin(ctx, flags));
     BHR_TRY(bhr_launch_march(ctx, cam, flags));  // records the ring slot's march events
     BHR_HIP(hipEventRecord(f.march_done, f.stream));
     if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctx));
     // the V kernel clears the counter cell BHR_MAX_FRAME_SLOTS frames ahead: no frame that may be in flight on another
     // slot's stream is counting into it (the next frames' marches may already be running)
     ctx->v_zero_cell = ctx->d_steps_ring + (size_t)((ring + BHR_MAX_FRAME_SLOTS) % BHR_TIMING_RING) * BHR_STEP_CELL;
-    const int32_t rc_v = bhr_launch_bloom_v(ctx, with_bloom);
+    // what the frame stores: the layers the context's consumers asked for (bhr_set_outputs); the lens flare works on the f32
+    // frame, so a flared frame keeps it and quantises afterwards
+    uint32_t want = ctx->out_want;
+    if (flags & BHR_LENS_FLARE) want = (want | BHR_OUT_F32) & ~BHR_OUT_U8;
+    const int32_t rc_v = bhr_frame_post(ctx, with_bloom, want);
     ctx->v_zero_cell = nullptr;
     BHR_TRY(rc_v);
     if (flags & BHR_LENS_FLARE) {
@@ -609,6 +722,7 @@ int32_t render_on_slot(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags, int 
         BHR_TRY(bhr_launch_flare_glow(ctx, true));
         BHR_TRY(bhr_launch_flare_sums(ctx));
         BHR_TRY(bhr_launch_flare_apply(ctx, nullptr));
+        if (ctx->out_want & BHR_OUT_U8) BHR_TRY(bhr_ensure_outputs(ctx, BHR_OUT_U8));
     }
     BHR_HIP(hipEventRecord(ctx->ring_ev[ring * 3 + 2], f.stream));
     BHR_HIP(hipEventRecord(f.done, f.stream));
@@ -652,10 +766,10 @@ int32_t bhr_read_layer(bhr_ctx *ctx, int32_t layer, float *out) {
     BHR_TRY(use_device(ctx));
     const float *src = nullptr;
     switch (layer) {
-        case BHR_LAYER_FINAL: src = ctx->d_final; break;
+        case BHR_LAYER_FINAL: src = ctx->d_final; BHR_TRY(bhr_ensure_outputs(ctx, BHR_OUT_F32)); break;
         case BHR_LAYER_BG: src = ctx->d_bg; break;
         case BHR_LAYER_DISK: src = ctx->d_disk; break;
-        case BHR_LAYER_BLUR: src = ctx->d_blur; break;
+        case BHR_LAYER_BLUR: src = ctx->d_blur; BHR_TRY(bhr_ensure_outputs(ctx, BHR_OUT_BLUR)); break;
         default: return bhr_fail(BHR_ERR_INVALID, "bhr_read_layer: unknown layer %d", layer);
     }
     return download(ctx, out, src, (size_t)ctx->rows * ctx->cfg.width * 3 * sizeof(float));
@@ -665,11 +779,12 @@ int32_t bhr_write_layer(bhr_ctx *ctx, int32_t layer, const float *in) {
     if (!ctx || !in) return bhr_fail(BHR_ERR_INVALID, "bhr_write_layer: bad argument");
     BHR_TRY(use_device(ctx));
     float *dst = nullptr;
+    bhr_frame_slot &f = ctx->slots[ctx->active_slot];
     switch (layer) {
-        case BHR_LAYER_FINAL: dst = ctx->d_final; break;
+        case BHR_LAYER_FINAL: dst = ctx->d_final; f.have = (f.have | BHR_OUT_F32) & ~BHR_OUT_U8; break;   // the u8 rows follow the written frame
         case BHR_LAYER_BG: dst = ctx->d_bg; break;
         case BHR_LAYER_DISK: dst = ctx->d_disk; break;
-        case BHR_LAYER_BLUR: dst = ctx->d_blur; break;
+        case BHR_LAYER_BLUR: dst = ctx->d_blur; f.have |= BHR_OUT_BLUR; break;
         default: return bhr_fail(BHR_ERR_INVALID, "bhr_write_layer: unknown layer %d", layer);
     }
     return upload(ctx, dst, in, (size_t)ctx->rows * ctx->cfg.width * 3 * sizeof(float));
@@ -680,10 +795,52 @@ int32_t bhr_bloom(bhr_ctx *ctx) {
     if (ctx->rows != ctx->cfg.height)
         return bhr_fail(BHR_ERR_INVALID, "bhr_bloom: needs a whole-frame context (rows %d of %d)", ctx->rows, ctx->cfg.height);
     BHR_TRY(use_device(ctx));
-    const char *only = getenv("BHR_BLOOM_ONLY");               // "h" / "v": one pass alone (tools/exp_bloom.py times them)
-    if (!(only && only[0] == 'v')) BHR_TRY(bhr_launch_bloom_h(ctx));
-    if (only && only[0] == 'h') return BHR_OK;
-    return bhr_launch_bloom_v(ctx, 1);
+    BHR_TRY(bhr_frame_begin(ctx, 0));                          // the context's arithmetic decides the kernels, as for a rendered frame
+    if (ctx->bloom_split) BHR_TRY(bhr_launch_bloom_pack(ctx)); // the disk layer may be the caller's (bhr_write_layer)
+    BHR_TRY(bhr_launch_bloom_h(ctx));
+    return bhr_frame_post(ctx, 1, BHR_OUT_F32 | BHR_OUT_BLUR);
+}
+
+int32_t bhr_debug_read(bhr_ctx *ctx, int32_t which, void *out, int64_t bytes, int32_t *geom) {
+    if (!ctx || bytes < 0) return bhr_fail(BHR_ERR_INVALID, "bhr_debug_read: bad argument");
+    BHR_TRY(use_device(ctx));
+    bhr_split_geom g;
+    bhr_split_geometry(ctx, &g);
+    if (geom) { geom[0] = g.NT; geom[1] = g.n_tx; geom[2] = g.WP; geom[3] = g.YB; geom[4] = g.GP; geom[5] = g.g0; geom[6] = g.t_first; geom[7] = g.n_ty; geom[8] = g.pbr; geom[9] = g.GR; }
+    const void *src = which == 0 ? ctx->d_pa : which == 1 ? ctx->d_pb : nullptr;
+    const size_t have = which == 0 ? g.pa_halfs * 2 : g.pb_halfs * 2;
+    if (!out || bytes == 0) return BHR_OK;
+    if (!src) return bhr_fail(BHR_ERR_STATE, "bhr_debug_read: buffer %d does not exist (no split-f16 frame yet)", which);
+    if ((size_t)bytes > have) return bhr_fail(BHR_ERR_INVALID, "bhr_debug_read: %lld bytes asked, the buffer holds %zu", (long long)bytes, have);
+    return download(ctx, out, src, (size_t)bytes);
+}
+
+int32_t bhr_set_option(bhr_ctx *ctx, const char *name, double value) {
+    if (!ctx || !name) return bhr_fail(BHR_ERR_INVALID, "bhr_set_option: bad argument");
+    const std::string n(name);
+    const int v = (int)value;
+    bhr_options &o = ctx->opt;
+    if (n == "bloom_split") o.bloom_split = v < 0 ? -1 : (v ? 1 : 0);
+    else if (n == "bloom_dbg") o.bloom_dbg = v;
+    else if (n == "bloom_tiles") o.bloom_tiles = v < 0 || v > 8 ? 0 : v;
+    else if (n == "hybrid_repair") o.hybrid_repair = v < 0 ? -1 : (v ? 1 : 0);
+    else if (n == "hybrid_band_lo") { if (!o.hybrid_band_set) o.hybrid_band[1] = 0.36; o.hybrid_band[0] = value; o.hybrid_band_set = 1; }
+    else if (n == "hybrid_band_hi") { if (!o.hybrid_band_set) o.hybrid_band[0] = 0.085; o.hybrid_band[1] = value; o.hybrid_band_set = 1; }
+    else if (n == "hybrid_band_default") o.hybrid_band_set = 0;
+    else if (n == "hybrid_streams") o.hybrid_streams = v == 1 ? 1 : 2;
+    else if (n == "mip_lds") o.mip_lds = v != 0;
+    else if (n == "tile_order_rows") o.tile_order_rows = v != 0;
+    else if (n == "group_threads") o.group_threads = v < 0 ? -1 : (v ? 1 : 0);
+    else if (n == "group_schedule") o.group_schedule = v < 0 ? -1 : (v ? 1 : 0);
+    else return bhr_fail(BHR_ERR_INVALID, "bhr_set_option: unknown option '%s'", name);
+    return BHR_OK;
+}
+
+int32_t bhr_set_outputs(bhr_ctx *ctx, uint32_t mask) {
+    if (!ctx || !(mask & (BHR_OUTPUT_F32 | BHR_OUTPUT_BLUR | BHR_OUTPUT_U8)) || (mask & ~(BHR_OUTPUT_F32 | BHR_OUTPUT_BLUR | BHR_OUTPUT_U8)))
+        return bhr_fail(BHR_ERR_INVALID, "bhr_set_outputs: mask %u", mask);
+    ctx->out_want = mask;
+    return BHR_OK;
 }
 
 int32_t bhr_lens_flare(bhr_ctx *ctx) {
@@ -691,6 +848,8 @@ int32_t bhr_lens_flare(bhr_ctx *ctx) {
     if (ctx->rows != ctx->cfg.height)
         return bhr_fail(BHR_ERR_INVALID, "bhr_lens_flare: needs a whole-frame context (rows %d of %d)", ctx->rows, ctx->cfg.height);
     BHR_TRY(use_device(ctx));
+    BHR_TRY(bhr_ensure_outputs(ctx, BHR_OUT_F32));
+    ctx->slots[ctx->active_slot].have &= ~BHR_OUT_U8;          // the u8 rows follow the flared frame
     BHR_TRY(bhr_launch_flare_glow(ctx, true));
     BHR_TRY(bhr_launch_flare_sums(ctx));
     return bhr_launch_flare_apply(ctx, nullptr);
@@ -716,7 +875,7 @@ int32_t bhr_read_gathered(bhr_ctx *ctx, float *out) {
 int32_t bhr_read_final_u8(bhr_ctx *ctx, uint8_t *out) {
     if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_read_final_u8: bad argument");
     BHR_TRY(use_device(ctx));
-    BHR_TRY(bhr_launch_quantize(ctx));
+    BHR_TRY(bhr_ensure_outputs(ctx, BHR_OUT_U8));
     return download(ctx, out, ctx->d_final_u8, (size_t)ctx->rows * ctx->cfg.width * 3);
 }
 

@@ -79,6 +79,8 @@ struct BhrMarchArgs {
     BhrScene sc;
     float *bg;               // (rows, width, 3)
     float *disk;             // (rows, width, 3)
+    _Float16 *diskp;         // non-null: the disk layer once more, cut into f16 halves in the bloom H pass's operand order (bloom.hip: pa)
+    int32_t dp_yb, dp_gp, dp_g0;
     unsigned long long *ray_steps;
     unsigned int *queue;     // persistent-wave work counter (zeroed before launch)
     const bhr_disk_v2_params *dv2;   // non-null: analytic Disk V2 source instead of the texture
@@ -110,6 +112,41 @@ struct bhr_march_part {
     int32_t repair;          // 1: the fast object's guard kernel (marks lanes on a discontinuity, appends them to the fix list); 2: the strict fix kernel over that list
 };
 
+// what a frame's V pass stores (bhr_launch_bloom_v_rows); bhr_ensure_outputs re-runs it for layers nobody asked for up front
+#define BHR_OUT_F32 1u    // clip(bg + disk + blur) as f32: what TaichiRenderer.render() returns
+#define BHR_OUT_BLUR 2u   // blur_field
+#define BHR_OUT_U8 4u     // the frame quantised as save_image does (render.py:423)
+
+// The library's environment switches, read ONCE by bhr_create (nothing on the bhr_render path calls getenv).
+struct bhr_options {
+    int32_t frame_slots;        // BHR_FRAME_SLOTS: frames in flight per context (1 or 2, default 2)
+    int32_t bloom_split;        // BHR_BLOOM_SPLIT: -1 by arithmetic (default), 0 exact f32 kernels always, 1 split-f16 always
+    int32_t bloom_dbg;          // experiments only
+    int32_t bloom_tiles;        // BHR_BLOOM_TILES: output tiles per wave of the split-f16 post-pass (1..8; 0 = by launch size), A/B runs
+    int32_t hybrid_repair;      // BHR_HYBRID_REPAIR: -1 by view (default), 0 / 1 guards + strict fix list off / on
+    double hybrid_band[2];      // BHR_HYBRID_BAND="lo,hi": strict band around b_c in r_s (default 0.085, 0.36)
+    int32_t hybrid_band_set;
+    int32_t hybrid_streams;     // BHR_HYBRID_STREAMS: 1 both lists of a hybrid march on one stream, 2 (default) on two
+    int32_t mip_lds;            // BHR_MIP_LDS=1: anti-aliased fast frames stage the coarse mip levels in LDS
+    int32_t tile_order_rows;    // BHR_TILE_ORDER=row: row-major march launch order (A/B runs)
+    int32_t tile_block;         // BHR_TILE_BLOCK: threads per march workgroup (64 / 128 / 256)
+    int32_t group_threads;      // BHR_GROUP_THREADS: -1 by device layout (default), 0 / 1 one submitting thread / one per tile
+    int32_t group_schedule;     // BHR_GROUP_SCHEDULE: -1 by flags (default), 0 serial, 1 pipelined
+    int32_t aux_priority, aux_per_slot;   // BHR_AUX_STREAMS="<priority>,<per slot>": the second march stream(s) of hybrid frames
+    int32_t stream_pad[3];      // BHR_STREAM_PAD="a,b,c": idle streams created in front of slot 0's, slot 1's, the second march streams (experiment)
+};
+
+// geometry of a context's split-f16 bloom buffers (bloom.hip)
+struct bhr_split_geom {
+    int32_t NT;            // 16-tap chunks either side of a tile: ceil(R / 16) + 1
+    int32_t n_tx, WP;      // 32-pixel tiles along x, W rounded up to them
+    int32_t YB, GP, g0;    // pa: 32-row blocks, 8-pixel groups per block (padded), zero groups in front
+    int32_t t_first, n_ty; // global 32-row tile of the block's first row, tiles it touches
+    int32_t pbr, GR;       // pb: global row of plane row 0 (multiple of 16, may be negative), 8-row groups
+    size_t pa_halfs, pb_halfs;
+    int32_t table_bytes;
+};
+
 // Frame slot: the buffers one frame in flight owns.  bhr_render alternates between two slots, each with its own
 // stream, so that the tail and the bloom of frame n run under the march of frame n + 1; the scene (skybox, mip
 // stack, comp planes ...) is shared and read-only while frames are in flight (bhr_enter orders every other entry
@@ -120,8 +157,11 @@ struct bhr_march_part {
 struct bhr_frame_slot {
     hipStream_t stream;
     float *d_bg, *d_disk, *d_hblur, *d_blur, *d_final;
-    float *d_hblur_base;       // the allocation d_hblur points BHR_HBLUR_PAD_ROWS rows into (zero rows in front of plane 0 and behind plane 2)
+    float *d_hblur_base;       // the allocation d_hblur points BHR_HBLUR_PAD_ROWS rows into (zero rows in front of plane 0 and behind plane 2); exact-f32 bloom, on first use
+    void *d_pa, *d_pb;         // split-f16 bloom (bloom.hip): the march's packed copy of the disk layer, the packed H-blur planes; on first use
     uint8_t *d_final_u8;
+    uint32_t have;             // BHR_OUT_* layers of the slot's last frame that are in memory (the V pass stores what was asked for; the rest on demand)
+    int32_t frame_split, frame_with_bloom;   // how that frame's post-pass ran (bhr_ensure_outputs re-runs its V pass)
     unsigned int *d_queue;
     // lens flare scratch of the frame (flare.hip): glow rows, their transpose, chunk sums, the three frame sums
     float *d_glow_hw, *d_glow_wh, *d_flare_c0;
@@ -191,11 +231,19 @@ struct bhr_ctx {
     uint8_t *d_final_u8;       // (rows, W, 3)
     float *d_wtab;             // bloom weights (3, R + pad)
     float *d_wext;             // unfolded weights (3, 2 R4 + 8)
-    unsigned short *d_wsplit;  // bf16 x 3 weight table, 9 parts x 8 shifted copies (bloom.hip: bloom_wsplit_kernel)
+    unsigned short *d_w16;     // split-f16 weight table: 3 channels x 2 halves x 8 shifted copies (bloom.hip: bloom_tables_kernel)
+    void *d_pa, *d_pb;         // the active slot's packed bloom operands (null until a split frame needs them)
     int32_t mip_lds_from;      // first mip level the last anti-aliased fast march staged in LDS (BHR_MIP_LDS), -1: none
-    int32_t bloom_split;       // post-pass of the current frame: 0 f32 kernels, 1 bf16 matrix cores per pass where they pay (fast / hybrid), 2 both passes
-    float *d_wsum_h;           // (3, W)
-    float *d_wsum_v;           // (3, H)
+    int32_t bloom_split;       // post-pass of the current frame: 0 exact f32 kernels (strict), 1 split-f16 matrix-core kernels (fast / hybrid)
+    int32_t split_ok;          // the context's radius fits the split kernels' table (R <= 176)
+    uint32_t out_want;         // BHR_OUT_* the frames of this context store (bhr_set_outputs; default: the f32 frame)
+    // rows of this block that neighbouring row blocks need for their V pass: the H pass writes them straight into those
+    // blocks' planes (set by group.hip for the duration of a group / tile render)
+    struct { void *pb; int32_t pbr, gr; } mirrors[6];
+    int32_t n_mirrors;
+    bhr_options opt;           // the BHR_* environment switches, read once by bhr_create
+    float *d_wsum_h;           // (3, W) in-bounds weight sums, then (3, W) the split H pass's multiplier 2^-10 / sum
+    float *d_wsum_v;           // (3, H), then (3, H) the split V pass's multiplier 2^-24 / sum
     int32_t bloom_R, bloom_ready;
     unsigned long long *d_ray_steps;
     unsigned int *d_queue;
@@ -278,11 +326,21 @@ int32_t bhr_ensure_tile_order(bhr_ctx *ctx);                                    
 int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);     // hybrid.hip
 void bhr_hybrid_free(bhr_ctx *ctx);
 int32_t bhr_bloom_prepare(bhr_ctx *ctx);
+int32_t bhr_split_nt(int32_t R);
+void bhr_split_geometry(const bhr_ctx *ctx, bhr_split_geom *g);
+int32_t bhr_launch_bloom_pack(bhr_ctx *ctx);                               // d_disk -> d_pa
 int32_t bhr_launch_bloom_h(bhr_ctx *ctx);
-int32_t bhr_launch_bloom_v(bhr_ctx *ctx, int32_t with_bloom);
-int32_t bhr_launch_bloom_h_rows(bhr_ctx *ctx, int32_t r0, int32_t r1);     // local rows [r0, r1)
-int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, int32_t r1, uint8_t *u8_out);
+// V pass + combine over local rows [r0, r1) storing the BHR_OUT_* layers in `want`; gather_u8 / gather_f32 non-null: the
+// u8 / f32 rows go into that (H, W, 3) frame buffer (a row-block gather, possibly on a peer device) instead of the context's own
+int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, int32_t r1, uint32_t want, uint8_t *gather_u8, float *gather_f32);
 int32_t bhr_bloom_v_tile_rows(bhr_ctx *ctx);                               // output rows per V-pass block
+int32_t bhr_activate_slot(bhr_ctx *ctx, int32_t k);                        // api.hip: points the launchers at frame slot k (allocating it)
+// api.hip: decides the frame's arithmetic / post-pass kernels and makes sure their buffers exist (before the march is launched)
+int32_t bhr_frame_begin(bhr_ctx *ctx, uint32_t flags);
+// api.hip: the whole-block V pass of a frame into the context's own buffers, recording what it stored
+int32_t bhr_frame_post(bhr_ctx *ctx, int32_t with_bloom, uint32_t want);
+// api.hip: makes the BHR_OUT_* layers in `need` of the active slot's last frame exist (re-runs its V pass for what is missing)
+int32_t bhr_ensure_outputs(bhr_ctx *ctx, uint32_t need);
 void bhr_pipe_free(bhr_ctx *ctx);                                          // group.hip
 int32_t bhr_ensure_pinned(bhr_ctx *ctx, size_t bytes);                     // api.hip
 // fork: the aux stream waits for everything ctx->stream has been given so far; join: ctx->stream waits for the aux stream
@@ -291,7 +349,7 @@ int32_t bhr_aux_join(bhr_ctx *ctx);
 int32_t bhr_launch_flare_glow(bhr_ctx *ctx, bool whole_frame);       // flare.hip
 int32_t bhr_launch_flare_sums(bhr_ctx *ctx);
 int32_t bhr_launch_flare_apply(bhr_ctx *ctx, const double *sums);    // sums == nullptr: device-resident totals
-int32_t bhr_launch_quantize(bhr_ctx *ctx);                           // api.hip: FINAL -> u8 on the stream
+int32_t bhr_launch_quantize(bhr_ctx *ctx);                           // api.hip: the frame's u8 rows, on the stream (from the V pass, or FINAL -> u8)
 // png_device.hip: (rows, W, 3) u8 at d_rgb -> PNG file bytes at d_out on ctx->stream; d_meta (4 words) = {length, error, ..}
 int32_t bhr_launch_png_encode(bhr_ctx *ctx, const uint8_t *d_rgb, uint8_t *d_out, int64_t cap, uint32_t *d_meta);
 void bhr_png_dev_free(bhr_ctx *ctx);

@@ -1,35 +1,34 @@
-// group.hip -- one frame in N row blocks (BASELINE.json configs[3]): bhr_group_render / bhr_group_render_subset.
+// group.hip -- one frame in N row blocks (BASELINE.json configs[3]): bhr_group_render / bhr_group_render_subset (one process
+// drives the devices) and bhr_tile_export / _connect / _render (one process per tile).
 //
 // The reference has no multi-GPU code; what has to be kept is the frame: march -> bloom H -> bloom V ->
 // clip(bg + disk + blur) (-> lens flare) of render.py:3865-3923, 3022-3114.  A row block needs R = int(0.02 W) rows of
-// its neighbours' H-blurred disk layer for the V pass; everything else is local.  Two schedules produce the same bytes:
+// its neighbours' H-blurred disk layer for the V pass; everything else is local.
 //
-//  * serial (BHR_GROUP_SERIAL, round 1-2): per tile march -> H pass -> halo pull -> V pass -> gather, each step behind
-//    the previous one on the tile's stream.  At 8 tiles of an 8k frame the steps after the march (H 0.12, halo 0.1,
-//    V 0.34, f32 gather 0.33 ms) are a 0.9 ms tail behind a 3.0 ms march.
-//  * pipelined: per tile three streams.
-//      tile stream   march -> H pass -> `halo_ready` -> V pass + combine in row chunks: the rows at least R away from a
-//                    neighbouring tile FIRST (they need no halo), the rows next to the edges once the halo has arrived;
-//                    each chunk's quantised bytes are written by the V kernel's epilogue (BHR_GATHER_U8);
-//      copy stream   pulls the neighbours' halo rows behind THEIR `halo_ready`, under the V pass of the middle rows;
-//      push stream   pushes every finished chunk into the frame buffer on tile 0's device while the next chunk's V
-//                    kernel runs.  u8 rows: 12.4 MB per 8k tile instead of 49.8 MB of f32.
-//    Default where the tiles sit on DISTINCT devices (the copies cross xGMI: ~0.09 ms halo + ~0.08 ms u8 rows of an 8k
-//    tile); tiles sharing one device default to the serial schedule -- their copies are HBM to HBM and every cross-stream
-//    hand-over costs more than it hides (tools/exp_tile_tail.py).  BHR_GROUP_SCHEDULE / BHR_GROUP_SERIAL override.
-//    Tried and removed: marching the halo bands in a launch of their own so that the pull starts under the march of the
-//    middle rows, H / V on a high-priority stream of their own -- the second launch's ragged start and the extra
-//    hand-overs cost an 8k tile 0.2-0.5 ms against the 0.09 ms they hide.
-//    The lens flare needs the frame's three sums (a host read-back on tile 0), so with BHR_LENS_FLARE the chunks stay on
-//    the device until the flare has been applied; march / H / halo / V are pipelined all the same.
+// Round 4: the kernels do the exchange.  Rounds 2-3 moved the halo rows and the finished rows with hipMemcpyPeerAsync
+// stages of their own (halo pull, u8 / f32 push), each behind a kernel boundary and a cross-stream hand-over: 0.2-0.28 ms
+// of tail behind a 1.2 ms march of an 8k tile.  Now
+//   * the H pass of a split-f16 frame (fast / hybrid arithmetic, bloom.hip) stores the rows a neighbouring block needs
+//     straight into that block's planes -- peer-mapped pointers in one process, hipIpcMemHandle mappings between
+//     processes -- next to its own copy (`mirrors`);
+//   * the V pass's epilogue stores the quantised u8 rows (BHR_GATHER_U8) or the f32 rows (BHR_GATHER_PEER) straight into
+//     the frame buffer on tile 0's device;
+//   so a tile's stream carries march -> H -> V and nothing else: the only cross-tile dependency left is "my V pass waits
+//   for my neighbours' H passes" -- one event wait (one shared-memory counter between processes).  The exact-f32
+//   post-pass of strict frames keeps its planar planes and pulls its halo rows with copies as before; its V pass stores
+//   into the frame buffer directly all the same.
+// Two schedules, same bytes: serial (the V pass in one launch behind the wait) and pipelined (the rows at least R away
+// from a neighbouring block go through the V pass FIRST, under the neighbours' H passes / the halo pull).  Default:
+// pipelined where the tiles sit on distinct devices, serial where they share one.  The lens flare needs the frame's three
+// sums (a host read-back on tile 0), so with BHR_LENS_FLARE the tiles keep their f32 rows until the flare has been
+// applied and ship them with copies afterwards.
 //
-// All exchanges are hipMemcpyPeerAsync between neighbours or onto tile 0 (xGMI point to point), no collective.  One
-// process drives the devices; `live` (bhr_group_render_subset) restricts a call to some tiles while the others keep the
-// buffers of the previous full render -- how one tile of eight is timed end to end on a single GPU (bench.py
-// tile_scaling.tile_tail_ms).
+// `live` (bhr_group_render_subset) restricts a call to some tiles while the others keep the buffers of the previous full
+// render -- how one tile of eight is timed end to end on a single GPU (bench.py tile_scaling.tile_tail_ms).
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,17 +40,18 @@ namespace {
 constexpr int PIPE_MAX_CHUNKS = 16;
 
 struct TilePipe {
-    hipStream_t copy, push;       // halo pulls; pushes of finished row chunks
-    hipEvent_t halo_ready, halo_in, v_done[PIPE_MAX_CHUNKS], landed;
-    // one-process-per-tile variant (bhr_tile_connect): the neighbours' H-blur planes and tile 0's frame buffers, opened
-    // from their IPC handles; counters in host shared memory for the hand-shakes
-    int32_t linked, rank, world;
-    float *nb_hblur[2];           // [0] the tile above, [1] the tile below (nullptr: none)
+    hipStream_t copy;             // halo pulls of the exact-f32 post-pass
+    hipEvent_t halo_ready, halo_in;
+    // one-process-per-tile variant (bhr_tile_connect): the neighbours' planes and tile 0's frame buffers, opened from their
+    // IPC handles; counters in host shared memory for the hand-shakes
+    int32_t linked, rank, world, split;
+    float *nb_hblur[2];           // exact-f32 post-pass: the planes of the tile above [0] / below [1] (nullptr: none)
     int32_t nb_rows[2];
+    struct { void *pb; int32_t pbr, gr; } nb_split[2];   // split-f16 post-pass: their packed planes
     float *gather_f32;            // frame buffers on tile 0's device (its own pointers on rank 0)
     uint8_t *gather_u8;
     void *opened[4];              // what hipIpcCloseMemHandle has to release
-    volatile uint64_t *shm;       // BHR_TILE_SHM_WORDS words per rank: [0] frames whose halo bands are H-blurred, [1] frames done
+    volatile uint64_t *shm;       // BHR_TILE_SHM_WORDS words per rank: [0] frames whose halo rows are H-blurred, [1] frames done
     uint64_t frame;               // frames rendered through bhr_tile_render
 };
 
@@ -72,55 +72,58 @@ int32_t ensure_pipe(bhr_ctx *ctx) {
     memset(p, 0, sizeof(*p));
     ctx->pipe = p;
     BHR_HIP(hipStreamCreateWithFlags(&p->copy, hipStreamNonBlocking));
-    BHR_HIP(hipStreamCreateWithFlags(&p->push, hipStreamNonBlocking));
-    hipEvent_t *evs[] = {&p->halo_ready, &p->halo_in, &p->landed};
+    hipEvent_t *evs[] = {&p->halo_ready, &p->halo_in};
     for (hipEvent_t *ev : evs) BHR_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    for (auto &ev : p->v_done) BHR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     return BHR_OK;
 }
 
 // Row chunks of a tile's V pass, in launch order.  Rows at least R away from a neighbouring tile need no halo rows: they
-// go first, under the halo pull; the rows next to the tile's edges follow once the halo has arrived.  Every chunk is
-// pushed to tile 0 while the next one's V kernel runs.  Chunk boundaries fall on multiples of the V kernel's block height.
+// go first, under the neighbours' H passes; the rows next to the tile's edges follow once the halo has arrived.  Chunk
+// boundaries fall on multiples of the V kernel's block height (in image rows where the kernel's tiles are global).
 struct Chunk { int r0, r1, needs_halo; };
-int plan_chunks(const bhr_ctx *c, bool has_up, bool has_down, int vb, Chunk (&out)[PIPE_MAX_CHUNKS]) {
-    const int rows = c->rows, R = c->bloom_R;
-    int want = 3;
-    if (const char *e = getenv("BHR_TILE_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= PIPE_MAX_CHUNKS - 2) want = v; }
+int plan_chunks(const bhr_ctx *c, bool has_up, bool has_down, int vb, bool pipelined, Chunk (&out)[PIPE_MAX_CHUNKS]) {
+    const int rows = c->rows;
+    if (!pipelined || (!has_up && !has_down)) { out[0] = Chunk{0, rows, (has_up || has_down) ? 1 : 0}; return 1; }
+    // reach of a neighbour's rows into this tile: the bloom radius, or the padded radius of the split kernels' 16-tap chunks
+    const int R = c->bloom_split ? 16 * (bhr_split_nt(c->bloom_R) - 1) : c->bloom_R;
     int n = 0;
-    auto add = [&](int r0, int r1, int halo, int pieces) {
-        if (r1 <= r0) return;
-        int step = ((r1 - r0 + pieces - 1) / pieces + vb - 1) / vb * vb;
-        for (int r = r0; r < r1 && n < PIPE_MAX_CHUNKS; r += step) out[n++] = Chunk{r, r + step < r1 ? r + step : r1, halo};
-    };
-    int m0 = has_up ? (R + vb - 1) / vb * vb : 0;
+    // first / last local row whose V-pass tile is clear of the neighbours: tiles are `vb` image rows, aligned globally
+    int m0 = 0, m1 = rows;
+    if (has_up) m0 = ((c->cfg.row0 + R + vb - 1) / vb) * vb - c->cfg.row0;
+    if (has_down) m1 = ((c->cfg.row0 + rows - R) / vb) * vb - c->cfg.row0;
     if (m0 > rows) m0 = rows;
-    int m1 = has_down ? m0 + ((rows - R - m0) > 0 ? (rows - R - m0) / vb * vb : 0) : rows;
-    if (m1 > rows) m1 = rows;
     if (m1 < m0) m1 = m0;
-    if (!has_up && !has_down) { add(0, rows, 0, want); return n; }
-    add(m0, m1, 0, want > 2 ? want - 2 : 1);       // the middle: no halo needed
-    add(0, m0, 1, 1);
-    add(m1, rows, 1, 1);
+    if (m1 > m0) out[n++] = Chunk{m0, m1, 0};       // the middle: no halo needed
+    if (m0 > 0) out[n++] = Chunk{0, m0, 1};
+    if (m1 < rows) out[n++] = Chunk{m1, rows, 1};
     return n;
 }
 
-// Direct xGMI copies between the tiles' devices: without peer access hipMemcpyPeerAsync stages through
-// host memory.  Tried once per ordered device pair; a refusal is not an error (the staged copy still works).
+// Direct xGMI stores / copies between the tiles' devices.  Tried once per ordered device pair; a refusal is not an error
+// for the copies (hipMemcpyPeerAsync then stages through the host) but rules the direct stores out (peer_ok).
+bool g_peer_ok[64][64];
 void enable_peer_access(bhr_ctx **ctxs, int32_t n) {
     static bool tried[64][64];
     for (int k = 0; k < n; ++k)
         for (int q = 0; q < n; ++q) {
             const int a = ctxs[k]->cfg.device, b = ctxs[q]->cfg.device;
-            if (a == b || a < 0 || b < 0 || a >= 64 || b >= 64 || tried[a][b]) continue;
+            if (a < 0 || b < 0 || a >= 64 || b >= 64) continue;
+            if (a == b) { g_peer_ok[a][b] = true; continue; }
+            if (tried[a][b]) continue;
             tried[a][b] = true;
             int can = 0;
             if (hipSetDevice(a) != hipSuccess || hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
                 (void)hipGetLastError();
                 continue;
             }
-            if (hipDeviceEnablePeerAccess(b, 0) != hipSuccess) (void)hipGetLastError();   // e.g. already enabled
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e != hipSuccess) (void)hipGetLastError();
+            g_peer_ok[a][b] = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
         }
+}
+bool peer_ok(const bhr_ctx *from, const bhr_ctx *to) {
+    const int a = from->cfg.device, b = to->cfg.device;
+    return a == b || (a >= 0 && b >= 0 && a < 64 && b < 64 && g_peer_ok[a][b]);
 }
 
 // runs f(k) for every live tile: one host thread per tile when the tiles sit on distinct devices (a single thread
@@ -151,10 +154,14 @@ int32_t for_tiles(int n, const int32_t *live, bool threaded, F f) {
     return BHR_OK;
 }
 
-// Halo pull of tile k: up to R rows of the H-blurred planes (planar (3, rows + 2R, W)) from the tiles above and below
-// (a tile thinner than R passes the request on to the next one), queued on `stream` behind the producers' events.
-// pipelined: behind the neighbour's `halo_ready` (its H pass), serial: behind its ev[3].
-int32_t queue_halo_pull(bhr_ctx **ctxs, int n, int k, hipStream_t stream, bool pipelined) {
+// does tile q's V pass read rows of tile k (k != q)?  Its planes reach `reach` rows past its own.
+bool needs_rows_of(const bhr_ctx *q, const bhr_ctx *k, int reach) {
+    return k->cfg.row1 > q->cfg.row0 - reach && k->cfg.row0 < q->cfg.row1 + reach;
+}
+
+// Exact-f32 post-pass: halo pull of tile k -- up to R rows of the planar (3, rows + 2R, W) H-blur planes from the tiles above
+// and below (a tile thinner than R passes the request on to the next one) -- queued on `stream` behind the producers' H passes.
+int32_t queue_halo_pull(bhr_ctx **ctxs, int n, int k, hipStream_t stream, const int32_t *live) {
     bhr_ctx *me = ctxs[k];
     const size_t R = me->bloom_R, W = me->cfg.width, my_rows = me->rows;
     for (int side = 0; side < 2; ++side) {
@@ -163,12 +170,9 @@ int32_t queue_halo_pull(bhr_ctx **ctxs, int n, int k, hipStream_t stream, bool p
         while (need > 0 && q >= 0 && q < n) {
             bhr_ctx *nb = ctxs[q];
             const size_t take = (size_t)nb->rows < need ? (size_t)nb->rows : need;
-            if (pipelined) {
-                const TilePipe *np = (const TilePipe *)nb->pipe;
-                if (np) BHR_HIP(hipStreamWaitEvent(stream, np->halo_ready, 0));   // a tile that never rendered pipelined has nothing in flight
-            } else {
-                BHR_HIP(hipStreamWaitEvent(stream, nb->ev[3], 0));
-            }
+            const TilePipe *np = (const TilePipe *)nb->pipe;
+            if (np && (!live || live[q])) BHR_HIP(hipStreamWaitEvent(stream, np->halo_ready, 0));   // a resting tile has nothing in flight
+            if (!nb->d_hblur) return bhr_fail(BHR_ERR_STATE, "group render: tile %d has no H-blur planes to pull from (render every tile once first)", q);
             const size_t nb_plane = ((size_t)nb->rows + 2 * R) * W, my_plane = (my_rows + 2 * R) * W;
             const size_t src_row = side == 0 ? R + nb->rows - take : R;          // neighbour's own rows live at [R, R + rows)
             const size_t dst_row = side == 0 ? R - got - take : R + my_rows + got;
@@ -209,6 +213,7 @@ int32_t flare_pass(bhr_ctx **ctxs, int n, const int32_t *live) {
         if (live && !live[k]) continue;
         BHR_HIP(hipSetDevice(ctxs[k]->cfg.device));
         BHR_TRY(bhr_launch_flare_apply(ctxs[k], tot));
+        ctxs[k]->slots[ctxs[k]->active_slot].have &= ~BHR_OUT_U8;
     }
     return BHR_OK;
 }
@@ -221,14 +226,14 @@ int32_t ensure_gather(bhr_ctx *head, uint32_t flags) {
     return BHR_OK;
 }
 
-// push local rows [r0, r1) of tile `t` into the frame buffers on `head` (f32 and / or u8), on `stream`
-int32_t queue_push(bhr_ctx *head, bhr_ctx *t, uint32_t flags, int r0, int r1, hipStream_t stream) {
-    const size_t W3 = (size_t)t->cfg.width * 3, off = (size_t)r0 * W3, cnt = (size_t)(r1 - r0) * W3;
-    const size_t dst = (size_t)(t->cfg.row0 + r0) * W3;
+// copy the rows of tile `t` into the frame buffers on `head` (f32 and / or u8), on `stream`: the flare path and tiles whose
+// device cannot store into tile 0's memory
+int32_t queue_push(bhr_ctx *head, bhr_ctx *t, uint32_t flags, hipStream_t stream) {
+    const size_t W3 = (size_t)t->cfg.width * 3, cnt = (size_t)t->rows * W3, dst = (size_t)t->cfg.row0 * W3;
     if (flags & BHR_GATHER_U8)
-        BHR_HIP(hipMemcpyPeerAsync(head->d_gather_u8 + dst, head->cfg.device, t->d_final_u8 + off, t->cfg.device, cnt, stream));
+        BHR_HIP(hipMemcpyPeerAsync(head->d_gather_u8 + dst, head->cfg.device, t->d_final_u8, t->cfg.device, cnt, stream));
     if (flags & BHR_GATHER_PEER)
-        BHR_HIP(hipMemcpyPeerAsync(head->d_gather + dst, head->cfg.device, t->d_final + off, t->cfg.device, cnt * sizeof(float), stream));
+        BHR_HIP(hipMemcpyPeerAsync(head->d_gather + dst, head->cfg.device, t->d_final, t->cfg.device, cnt * sizeof(float), stream));
     return BHR_OK;
 }
 
@@ -254,119 +259,124 @@ int32_t finish(bhr_ctx **ctxs, int n, const int32_t *live, float *out_host) {
     return BHR_OK;
 }
 
-// ---- serial schedule (rounds 1-2) ---------------------------------------------------------------------------------
-int32_t render_serial(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flags, float *out_host, const int32_t *live,
-                      bool threaded) {
-    const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
-    BHR_TRY(for_tiles(n, live, threaded, [&](int k) -> int32_t {
-        BHR_TRY(bhr_enter(ctxs[k]));
-        ctxs[k]->cur_slot = -1;
-        ctxs[k]->last_slot = -1;
-        BHR_TRY(bhr_launch_march(ctxs[k], cam, flags));
-        if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctxs[k]));
-        BHR_HIP(hipEventRecord(ctxs[k]->ev[3], ctxs[k]->stream));
-        return BHR_OK;
-    }));
-    if (with_bloom && n > 1)
-        for (int k = 0; k < n; ++k) {
-            if (live && !live[k]) continue;
-            BHR_TRY(bhr_enter(ctxs[k]));
-            BHR_TRY(queue_halo_pull(ctxs, n, k, ctxs[k]->stream, false));
-        }
-    for (int k = 0; k < n; ++k) {
-        if (live && !live[k]) continue;
-        BHR_TRY(bhr_enter(ctxs[k]));
-        BHR_TRY(bhr_launch_bloom_v(ctxs[k], with_bloom));
-        ctxs[k]->last_flags = (int32_t)flags;
-        ctxs[k]->timing_valid = 1;
+// the planes of the other tiles that hold rows of tile k: its H pass writes them there itself
+int32_t set_mirrors(bhr_ctx **ctxs, int n, int k) {
+    bhr_ctx *c = ctxs[k];
+    c->n_mirrors = 0;
+    if (!c->bloom_split) return BHR_OK;
+    const int reach = 16 * (bhr_split_nt(c->bloom_R) - 1);
+    for (int q = 0; q < n; ++q) {
+        if (q == k || !needs_rows_of(ctxs[q], c, reach + 32)) continue;   // + 32: planes start on 32-row tile boundaries
+        bhr_ctx *nb = ctxs[q];
+        void *pb = nb->slots[0].d_pb;
+        if (!pb) continue;                                                  // a tile that has never rendered a split frame
+        if (!peer_ok(c, nb)) return bhr_fail(BHR_ERR_STATE, "group render: device %d cannot store into device %d's memory (no peer access)", c->cfg.device, nb->cfg.device);
+        bhr_split_geom g;
+        bhr_split_geometry(nb, &g);
+        if (c->n_mirrors >= (int)(sizeof(c->mirrors) / sizeof(c->mirrors[0])))
+            return bhr_fail(BHR_ERR_INVALID, "group render: tile %d feeds more than %d neighbouring tiles (row blocks thinner than the bloom radius / 3?)", k, c->n_mirrors);
+        c->mirrors[c->n_mirrors].pb = pb;
+        c->mirrors[c->n_mirrors].pbr = g.pbr;
+        c->mirrors[c->n_mirrors].gr = g.GR;
+        c->n_mirrors += 1;
     }
-    if (flags & BHR_LENS_FLARE) BHR_TRY(flare_pass(ctxs, n, live));
-    if (flags & (BHR_GATHER_PEER | BHR_GATHER_U8)) {
-        BHR_TRY(ensure_gather(ctxs[0], flags));
-        for (int k = 0; k < n; ++k) {
-            if (live && !live[k]) continue;
-            BHR_TRY(bhr_enter(ctxs[k]));
-            if (flags & BHR_GATHER_U8) BHR_TRY(bhr_launch_quantize(ctxs[k]));
-            BHR_TRY(queue_push(ctxs[0], ctxs[k], flags, 0, ctxs[k]->rows, ctxs[k]->stream));
-        }
-    }
-    for (int k = 0; k < n; ++k) {
-        if (live && !live[k]) continue;
-        BHR_HIP(hipSetDevice(ctxs[k]->cfg.device));
-        BHR_HIP(hipEventRecord(ctxs[k]->ev[2], ctxs[k]->stream));
-    }
-    return finish(ctxs, n, live, out_host);
+    return BHR_OK;
 }
 
-// ---- pipelined schedule ---------------------------------------------------------------------------------------------
-int32_t render_pipelined(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flags, float *out_host, const int32_t *live,
-                         bool threaded) {
+int32_t render_tiles(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flags, float *out_host, const int32_t *live,
+                     bool threaded, bool pipelined) {
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     const bool flare = (flags & BHR_LENS_FLARE) != 0;
     const bool gather = (flags & (BHR_GATHER_PEER | BHR_GATHER_U8)) != 0;
     bhr_ctx *head = ctxs[0];
     if (gather) BHR_TRY(ensure_gather(head, flags));
 
-    // phase 1: march and H pass on the tile's stream
-    BHR_TRY(for_tiles(n, live, threaded, [&](int k) -> int32_t {
+    // every tile chooses its post-pass kernels and makes sure their buffers exist BEFORE any H pass may store into them
+    for (int k = 0; k < n; ++k) {
+        if (live && !live[k]) continue;
         bhr_ctx *c = ctxs[k];
         BHR_TRY(bhr_enter(c));
+        BHR_TRY(bhr_activate_slot(c, 0));
         c->cur_slot = -1;
         c->last_slot = -1;
         BHR_TRY(ensure_pipe(c));
+        BHR_TRY(bhr_frame_begin(c, flags));
+    }
+    const bool halo = with_bloom && n > 1;
+    if (halo)
+        for (int k = 0; k < n; ++k)
+            if (!live || live[k]) BHR_TRY(set_mirrors(ctxs, n, k));
+
+    // phase 1: march and H pass (+ the neighbours' halo rows of a split frame) on the tile's stream
+    BHR_TRY(for_tiles(n, live, threaded, [&](int k) -> int32_t {
+        bhr_ctx *c = ctxs[k];
+        BHR_HIP(hipSetDevice(c->cfg.device));
         TilePipe *p = (TilePipe *)c->pipe;
         BHR_TRY(bhr_launch_march(c, cam, flags));
         if (with_bloom) BHR_TRY(bhr_launch_bloom_h(c));
         BHR_HIP(hipEventRecord(p->halo_ready, c->stream));
         return BHR_OK;
     }));
+    for (int k = 0; k < n; ++k)
+        if (!live || live[k]) ctxs[k]->n_mirrors = 0;
 
-    // phase 2: halo pulls on the copy streams, behind the neighbours' halo_ready
-    if (with_bloom && n > 1)
+    // phase 2 (exact-f32 post-pass only): halo pulls behind the neighbours' H passes -- under the V pass of the middle rows
+    // (copy stream) in the pipelined schedule
+    if (halo)
         for (int k = 0; k < n; ++k) {
-            if (live && !live[k]) continue;
+            if ((live && !live[k]) || ctxs[k]->bloom_split) continue;
             TilePipe *p = (TilePipe *)ctxs[k]->pipe;
             BHR_HIP(hipSetDevice(ctxs[k]->cfg.device));
-            BHR_TRY(queue_halo_pull(ctxs, n, k, p->copy, true));
-            BHR_HIP(hipEventRecord(p->halo_in, p->copy));
+            hipStream_t s = pipelined ? p->copy : ctxs[k]->stream;
+            if (pipelined) BHR_HIP(hipStreamWaitEvent(s, p->halo_ready, 0));        // the pulls overwrite halo rows: behind this tile's own H pass too
+            BHR_TRY(queue_halo_pull(ctxs, n, k, s, live));
+            BHR_HIP(hipEventRecord(p->halo_in, s));
         }
 
-    // phase 3: V pass + combine in row chunks -- the rows that need no halo first, under the halo pull -- every finished
-    // chunk pushed by the push stream while the next chunk's V kernel runs
+    // phase 3: V pass + combine, storing straight into the frame buffers on tile 0's device where it may
     for (int k = 0; k < n; ++k) {
         if (live && !live[k]) continue;
         bhr_ctx *c = ctxs[k];
         TilePipe *p = (TilePipe *)c->pipe;
         BHR_HIP(hipSetDevice(c->cfg.device));
-        const bool halo = with_bloom && n > 1;
+        const bool direct = gather && !flare && !out_host && peer_ok(c, head);
+        uint32_t want = 0;
+        if (direct) want = ((flags & BHR_GATHER_U8) ? BHR_OUT_U8 : 0u) | ((flags & BHR_GATHER_PEER) ? BHR_OUT_F32 : 0u);
+        else want = BHR_OUT_F32 | ((gather && !flare && (flags & BHR_GATHER_U8)) ? BHR_OUT_U8 : 0u);
         Chunk chunks[PIPE_MAX_CHUNKS];
-        const int n_chunks = plan_chunks(c, halo && k > 0, halo && k < n - 1, bhr_bloom_v_tile_rows(c), chunks);
-        const bool push_chunks = gather && !flare;
+        const int n_chunks = plan_chunks(c, halo && k > 0, halo && k < n - 1, bhr_bloom_v_tile_rows(c), pipelined, chunks);
         bool waited = false;
+        auto wait_halo = [&]() -> int32_t {
+            if (waited || !halo) return BHR_OK;
+            waited = true;
+            if (!c->bloom_split) { BHR_HIP(hipStreamWaitEvent(c->stream, p->halo_in, 0)); return BHR_OK; }
+            const int reach = 16 * (bhr_split_nt(c->bloom_R) - 1) + 32;
+            for (int q = 0; q < n; ++q) {
+                if (q == k || (live && !live[q]) || !needs_rows_of(c, ctxs[q], reach)) continue;
+                BHR_HIP(hipStreamWaitEvent(c->stream, ((TilePipe *)ctxs[q]->pipe)->halo_ready, 0));
+            }
+            return BHR_OK;
+        };
         for (int ci = 0; ci < n_chunks; ++ci) {
-            if (chunks[ci].needs_halo && !waited) { BHR_HIP(hipStreamWaitEvent(c->stream, p->halo_in, 0)); waited = true; }
-            BHR_TRY(bhr_launch_bloom_v_rows(c, with_bloom, chunks[ci].r0, chunks[ci].r1, (push_chunks && (flags & BHR_GATHER_U8)) ? c->d_final_u8 : nullptr));
-            if (!push_chunks) continue;
-            BHR_HIP(hipEventRecord(p->v_done[ci], c->stream));
-            BHR_HIP(hipStreamWaitEvent(p->push, p->v_done[ci], 0));
-            BHR_TRY(queue_push(head, c, flags, chunks[ci].r0, chunks[ci].r1, p->push));
+            if (chunks[ci].needs_halo) BHR_TRY(wait_halo());
+            BHR_TRY(bhr_launch_bloom_v_rows(c, with_bloom, chunks[ci].r0, chunks[ci].r1, want, direct ? head->d_gather_u8 : nullptr,
+                                            direct ? head->d_gather : nullptr));
         }
-        if (halo && !waited) BHR_HIP(hipStreamWaitEvent(c->stream, p->halo_in, 0));   // nothing of this frame stays in flight
-        BHR_HIP(hipEventRecord(p->landed, p->push));
-        BHR_HIP(hipStreamWaitEvent(c->stream, p->landed, 0));
+        BHR_TRY(wait_halo());                                         // nothing of this frame stays in flight
+        c->slots[c->active_slot].have = direct ? 0u : want;           // what sits in the tile's OWN buffers
         c->last_flags = (int32_t)flags;
         c->timing_valid = 1;
     }
-    if (flare) {
-        BHR_TRY(flare_pass(ctxs, n, live));
-        if (gather)
-            for (int k = 0; k < n; ++k) {
-                if (live && !live[k]) continue;
-                BHR_TRY(bhr_enter(ctxs[k]));
-                if (flags & BHR_GATHER_U8) BHR_TRY(bhr_launch_quantize(ctxs[k]));
-                BHR_TRY(queue_push(head, ctxs[k], flags, 0, ctxs[k]->rows, ctxs[k]->stream));
-            }
-    }
+    if (flare) BHR_TRY(flare_pass(ctxs, n, live));
+    if (gather)
+        for (int k = 0; k < n; ++k) {
+            if (live && !live[k]) continue;
+            bhr_ctx *c = ctxs[k];
+            if (!flare && !out_host && peer_ok(c, head)) continue;    // stored directly
+            BHR_HIP(hipSetDevice(c->cfg.device));
+            if (flags & BHR_GATHER_U8) BHR_TRY(bhr_ensure_outputs(c, BHR_OUT_U8));
+            BHR_TRY(queue_push(head, c, flags, c->stream));
+        }
     for (int k = 0; k < n; ++k) {
         if (live && !live[k]) continue;
         BHR_HIP(hipSetDevice(ctxs[k]->cfg.device));
@@ -375,19 +385,34 @@ int32_t render_pipelined(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t 
     return finish(ctxs, n, live, out_host);
 }
 
+// nothing may be queued against the mappings when they are closed
+void drain(bhr_ctx *ctx, TilePipe *p) {
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->scene_stream) (void)hipStreamSynchronize(ctx->scene_stream);
+    if (ctx->stream && ctx->stream != ctx->scene_stream) (void)hipStreamSynchronize(ctx->stream);
+    if (p && p->copy) (void)hipStreamSynchronize(p->copy);
+}
+
+void close_mappings(bhr_ctx *ctx, TilePipe *p) {
+    drain(ctx, p);
+    for (void *&o : p->opened) {
+        if (o) (void)hipIpcCloseMemHandle(o);
+        o = nullptr;
+    }
+    p->nb_hblur[0] = p->nb_hblur[1] = nullptr;
+    p->nb_split[0].pb = p->nb_split[1].pb = nullptr;
+    p->linked = 0;
+}
+
 }  // namespace
 
 void bhr_pipe_free(bhr_ctx *ctx) {
     TilePipe *p = (TilePipe *)ctx->pipe;
     if (!p) return;
-    for (void *o : p->opened)
-        if (o) (void)hipIpcCloseMemHandle(o);
-    if (p->copy) { (void)hipStreamSynchronize(p->copy); (void)hipStreamDestroy(p->copy); }
-    if (p->push) { (void)hipStreamSynchronize(p->push); (void)hipStreamDestroy(p->push); }
-    hipEvent_t evs[] = {p->halo_ready, p->halo_in, p->landed};
+    close_mappings(ctx, p);
+    if (p->copy) (void)hipStreamDestroy(p->copy);
+    hipEvent_t evs[] = {p->halo_ready, p->halo_in};
     for (hipEvent_t ev : evs)
-        if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : p->v_done)
         if (ev) (void)hipEventDestroy(ev);
     delete p;
     ctx->pipe = nullptr;
@@ -418,13 +443,16 @@ int32_t bhr_group_render_subset(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam
         for (int q = 0; q < k; ++q)
             if ((!live || live[q]) && ctxs[k]->cfg.device == ctxs[q]->cfg.device) distinct_devices = false;
     }
+    const bhr_options &opt = ctxs[0]->opt;
     bool threaded = n_live > 1 && distinct_devices;
-    if (const char *e = getenv("BHR_GROUP_THREADS")) threaded = n_live > 1 && atoi(e) != 0;   // test knob: force / forbid
-    // tiles that share a device copy HBM to HBM: nothing to hide, the serial schedule has fewer hand-overs
-    bool serial = (flags & BHR_GROUP_SERIAL) != 0 || (!(flags & BHR_GROUP_PIPELINED) && !distinct_devices);
-    if (const char *e = getenv("BHR_GROUP_SCHEDULE")) serial = e[0] == 's';                   // "serial" | "pipelined": A/B runs
-    return serial ? render_serial(ctxs, n, cam, flags, out_host, live, threaded)
-                  : render_pipelined(ctxs, n, cam, flags, out_host, live, threaded);
+    if (opt.group_threads >= 0) threaded = n_live > 1 && opt.group_threads != 0;              // BHR_GROUP_THREADS: test knob, force / forbid
+    // explicit flags win; without them BHR_GROUP_SCHEDULE decides, else: pipelined where the tiles sit on distinct devices
+    // (something to hide), serial where they share one (fewer launches)
+    bool pipelined = distinct_devices;
+    if (opt.group_schedule >= 0) pipelined = opt.group_schedule != 0;
+    if (flags & BHR_GROUP_SERIAL) pipelined = false;
+    else if (flags & BHR_GROUP_PIPELINED) pipelined = true;
+    return render_tiles(ctxs, n, cam, flags, out_host, live, threaded, pipelined);
 }
 
 int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host) {
@@ -432,19 +460,31 @@ int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint3
 }
 
 // ---- one process per tile (bench.py --strong under torchrun when a rank sees only its own GPU) -------------------------
-// Same frame, same kernels, same three streams as the pipelined schedule above; what changes is who talks to whom.  Every
-// rank owns ONE tile.  Device memory crosses the process boundary through hipIpcMemHandle (the neighbours' H-blur planes
-// for the halo pull, tile 0's frame buffers for the push); ordering crosses it through two counters per rank in host
-// shared memory: a rank waits on the HOST for its own halo_ready event, publishes the frame number, and its neighbours
-// queue their halo pulls once they have seen it -- the data is complete by then, no inter-process event is needed.  The
-// frame ends with every rank synchronising its streams and publishing `done`; rank 0 returns when all have.
+// Same frame, same kernels as above; what changes is who talks to whom.  Every rank owns ONE tile.  Device memory crosses
+// the process boundary through hipIpcMemHandle -- the neighbours' planes (the H pass of a split frame stores its halo rows
+// into them; an exact-f32 frame pulls from them) and tile 0's frame buffers (the V pass stores into them) -- ordering
+// crosses it through two counters per rank in host shared memory: a rank waits on the HOST for its own H pass, publishes
+// the frame number, and launches the V pass of its edge rows once its neighbours have published theirs -- the halo rows
+// are complete by then, no inter-process event is needed.  The frame ends with every rank synchronising its stream and
+// publishing `done`; a rank returns when all have (nobody stores into a neighbour's planes while they are still read).
 int32_t bhr_tile_export(bhr_ctx *ctx, uint32_t gather_flags, bhr_tile_handles *out) {
     if (!ctx || !out) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_export: bad argument");
     BHR_TRY(bhr_enter(ctx));
+    BHR_TRY(bhr_activate_slot(ctx, 0));                                      // tile renders use slot 0, whatever bhr_render left active
+    BHR_TRY(bhr_frame_begin(ctx, 0));                                        // the context's arithmetic picks the post-pass, allocates its planes
     memset(out, 0, sizeof(*out));
     static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(out->hblur), "handle size");
     hipIpcMemHandle_t h;
-    BHR_HIP(hipIpcGetMemHandle(&h, ctx->slots[ctx->active_slot].d_hblur_base));   // handles name allocations: the planes start BHR_HBLUR_PAD_ROWS rows in
+    if (ctx->bloom_split) {
+        bhr_split_geom g;
+        bhr_split_geometry(ctx, &g);
+        BHR_HIP(hipIpcGetMemHandle(&h, ctx->slots[0].d_pb));
+        out->reserved[0] = 1;
+        out->reserved[1] = g.pbr;
+        out->reserved[2] = g.GR;
+    } else {
+        BHR_HIP(hipIpcGetMemHandle(&h, ctx->slots[0].d_hblur_base));        // handles name allocations: the planes start BHR_HBLUR_PAD_ROWS rows in
+    }
     memcpy(out->hblur, &h, sizeof(h));
     out->row0 = ctx->cfg.row0;
     out->rows = ctx->rows;
@@ -468,22 +508,24 @@ int32_t bhr_tile_export(bhr_ctx *ctx, uint32_t gather_flags, bhr_tile_handles *o
 int32_t bhr_tile_connect(bhr_ctx *ctx, int32_t rank, int32_t world, const bhr_tile_handles *all, uint64_t *shm) {
     if (!ctx || !all || !shm || world < 1 || rank < 0 || rank >= world) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: bad argument");
     BHR_TRY(bhr_enter(ctx));
+    BHR_TRY(bhr_activate_slot(ctx, 0));
+    BHR_TRY(bhr_frame_begin(ctx, 0));
+    const int split = ctx->bloom_split;
+    const int min_rows = split ? 16 * bhr_split_nt(ctx->bloom_R) + 16 : ctx->bloom_R;   // a tile's planes must not reach past its neighbours
     int expect = 0;
     for (int k = 0; k < world; ++k) {
         if (all[k].row0 != expect) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: tile %d starts at row %d, expected %d", k, all[k].row0, expect);
         expect += all[k].rows;
-        if (world > 1 && all[k].rows < ctx->bloom_R)
-            return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: tile %d has %d rows, fewer than the bloom radius %d (use bhr_group_render)", k, all[k].rows, ctx->bloom_R);
+        if (world > 1 && all[k].rows < min_rows)
+            return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: tile %d has %d rows, fewer than the %d the bloom's halo spans (use bhr_group_render)", k, all[k].rows, min_rows);
+        if (all[k].reserved[0] != split) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: tile %d runs the other post-pass arithmetic", k);
     }
     if (expect != ctx->cfg.height || all[rank].row0 != ctx->cfg.row0 || all[rank].rows != ctx->rows)
         return bhr_fail(BHR_ERR_INVALID, "bhr_tile_connect: the handles do not describe this frame / this rank's tile");
     const int with_up = rank > 0, with_down = rank < world - 1;
     BHR_TRY(ensure_pipe(ctx));
     TilePipe *p = (TilePipe *)ctx->pipe;
-    for (void *&o : p->opened) {
-        if (o) (void)hipIpcCloseMemHandle(o);
-        o = nullptr;
-    }
+    close_mappings(ctx, p);                                                  // a re-connect: drained first
     auto open = [&](const uint8_t *raw, void **out, int slot) -> int32_t {
         hipIpcMemHandle_t h;
         memcpy(&h, raw, sizeof(h));
@@ -491,10 +533,21 @@ int32_t bhr_tile_connect(bhr_ctx *ctx, int32_t rank, int32_t world, const bhr_ti
         p->opened[slot] = *out;
         return BHR_OK;
     };
-    p->nb_hblur[0] = p->nb_hblur[1] = nullptr;
-    const size_t pad = (size_t)BHR_HBLUR_PAD_ROWS * ctx->cfg.width;     // the handle opens the allocation; the planes start `pad` floats in
-    if (with_up) { BHR_TRY(open(all[rank - 1].hblur, (void **)&p->nb_hblur[0], 0)); p->nb_hblur[0] += pad; p->nb_rows[0] = all[rank - 1].rows; }
-    if (with_down) { BHR_TRY(open(all[rank + 1].hblur, (void **)&p->nb_hblur[1], 1)); p->nb_hblur[1] += pad; p->nb_rows[1] = all[rank + 1].rows; }
+    const size_t pad = (size_t)BHR_HBLUR_PAD_ROWS * ctx->cfg.width;     // the handle opens the allocation; the f32 planes start `pad` floats in
+    for (int side = 0; side < 2; ++side) {
+        if (!(side == 0 ? with_up : with_down)) continue;
+        const bhr_tile_handles &nb = all[side == 0 ? rank - 1 : rank + 1];
+        void *base = nullptr;
+        BHR_TRY(open(nb.hblur, &base, side));
+        if (split) {
+            p->nb_split[side].pb = base;
+            p->nb_split[side].pbr = nb.reserved[1];
+            p->nb_split[side].gr = nb.reserved[2];
+        } else {
+            p->nb_hblur[side] = (float *)base + pad;
+            p->nb_rows[side] = nb.rows;
+        }
+    }
     p->gather_f32 = ctx->d_gather;
     p->gather_u8 = ctx->d_gather_u8;
     if (rank != 0) {
@@ -505,6 +558,7 @@ int32_t bhr_tile_connect(bhr_ctx *ctx, int32_t rank, int32_t world, const bhr_ti
     }
     p->rank = rank;
     p->world = world;
+    p->split = split;
     p->shm = shm;
     p->frame = 0;
     p->linked = 1;
@@ -512,81 +566,82 @@ int32_t bhr_tile_connect(bhr_ctx *ctx, int32_t rank, int32_t world, const bhr_ti
 }
 
 namespace {
-// spins until the counter has reached `want`; gives up after ~20 s (a rank that died must not hang the others for ever)
+// waits until the counter has reached `want`; gives up after 20 s of wall-clock time (a rank that died must not hang the
+// others for ever)
 int32_t wait_counter(volatile uint64_t *c, uint64_t want, const char *what, int peer) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(20);
     for (uint64_t spins = 0; __atomic_load_n(c, __ATOMIC_ACQUIRE) < want; ++spins) {
-        if ((spins & 0xffff) == 0xffff) {
+        if ((spins & 0xfff) == 0xfff) {
             std::this_thread::yield();
-            if (spins > (1ull << 33)) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: timed out waiting for rank %d (%s)", peer, what);
+            if (std::chrono::steady_clock::now() > deadline)
+                return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: timed out waiting for rank %d (%s)", peer, what);
         }
     }
     return BHR_OK;
 }
-}  // namespace
 
-int32_t bhr_tile_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
-    if (!ctx || !cam) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_render: bad argument");
-    TilePipe *p = (TilePipe *)ctx->pipe;
-    if (!p || !p->linked) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: call bhr_tile_connect first");
-    if (flags & BHR_LENS_FLARE) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_render: the lens flare needs the one-process path (bhr_group_render)");
-    if ((flags & BHR_GATHER_PEER) && !p->gather_f32) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: no f32 frame buffer was exported by rank 0");
-    if ((flags & BHR_GATHER_U8) && !p->gather_u8) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: no u8 frame buffer was exported by rank 0");
+int32_t tile_render_linked(bhr_ctx *ctx, TilePipe *p, const bhr_camera *cam, uint32_t flags) {
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     const int rank = p->rank, world = p->world;
     const size_t R = ctx->bloom_R, W = ctx->cfg.width, rows = ctx->rows;
     const uint64_t frame = ++p->frame;
     volatile uint64_t *mine = p->shm + (size_t)rank * BHR_TILE_SHM_WORDS;
     BHR_TRY(bhr_enter(ctx));
+    BHR_TRY(bhr_activate_slot(ctx, 0));
     ctx->cur_slot = -1;
     ctx->last_slot = -1;
-    // march -> H pass on the tile's stream
-    BHR_TRY(bhr_launch_march(ctx, cam, flags));
-    if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctx));
-    BHR_HIP(hipEventRecord(p->halo_ready, ctx->stream));
+    BHR_TRY(bhr_frame_begin(ctx, flags));
+    if (with_bloom && ctx->bloom_split != p->split)
+        return bhr_fail(BHR_ERR_INVALID, "bhr_tile_render: the flags select the other post-pass arithmetic than the one the tiles were connected for");
     const bool halo = with_bloom && world > 1;
-    const bool gather = (flags & (BHR_GATHER_PEER | BHR_GATHER_U8)) != 0;
+    ctx->n_mirrors = 0;
+    if (halo && p->split)
+        for (int side = 0; side < 2; ++side)
+            if (p->nb_split[side].pb) {
+                ctx->mirrors[ctx->n_mirrors].pb = p->nb_split[side].pb;
+                ctx->mirrors[ctx->n_mirrors].pbr = p->nb_split[side].pbr;
+                ctx->mirrors[ctx->n_mirrors].gr = p->nb_split[side].gr;
+                ctx->n_mirrors += 1;
+            }
+    // march -> H pass (the neighbours' halo rows with it) on the tile's stream
+    int32_t rc = bhr_launch_march(ctx, cam, flags);
+    if (rc == BHR_OK && with_bloom) rc = bhr_launch_bloom_h(ctx);
+    ctx->n_mirrors = 0;
+    BHR_TRY(rc);
+    BHR_HIP(hipEventRecord(p->halo_ready, ctx->stream));
+    uint32_t want = ((flags & BHR_GATHER_U8) ? BHR_OUT_U8 : 0u) | ((flags & BHR_GATHER_PEER) ? BHR_OUT_F32 : 0u);
+    const bool direct = want != 0;
+    if (!direct) want = ctx->out_want;
     Chunk chunks[PIPE_MAX_CHUNKS];
-    const int n_chunks = plan_chunks(ctx, halo && rank > 0, halo && rank < world - 1, bhr_bloom_v_tile_rows(ctx), chunks);
-    // V pass + combine of chunk ci on the tile's stream, its rows pushed into tile 0's frame buffers by the push stream
+    const int n_chunks = plan_chunks(ctx, halo && rank > 0, halo && rank < world - 1, bhr_bloom_v_tile_rows(ctx), true, chunks);
     auto v_chunk = [&](int ci) -> int32_t {
-        const int r0 = chunks[ci].r0, r1 = chunks[ci].r1;
-        BHR_TRY(bhr_launch_bloom_v_rows(ctx, with_bloom, r0, r1, (flags & BHR_GATHER_U8) ? ctx->d_final_u8 : nullptr));
-        if (!gather) return BHR_OK;
-        BHR_HIP(hipEventRecord(p->v_done[ci], ctx->stream));
-        BHR_HIP(hipStreamWaitEvent(p->push, p->v_done[ci], 0));
-        const size_t W3 = W * 3, off = (size_t)r0 * W3, cnt = (size_t)(r1 - r0) * W3, dst = (size_t)(ctx->cfg.row0 + r0) * W3;
-        if (flags & BHR_GATHER_U8)
-            BHR_HIP(hipMemcpyAsync(p->gather_u8 + dst, ctx->d_final_u8 + off, cnt, hipMemcpyDeviceToDevice, p->push));
-        if (flags & BHR_GATHER_PEER)
-            BHR_HIP(hipMemcpyAsync(p->gather_f32 + dst, ctx->d_final + off, cnt * sizeof(float), hipMemcpyDeviceToDevice, p->push));
-        return BHR_OK;
+        return bhr_launch_bloom_v_rows(ctx, with_bloom, chunks[ci].r0, chunks[ci].r1, want, direct ? p->gather_u8 : nullptr, direct ? p->gather_f32 : nullptr);
     };
     // the rows that need no halo are queued now: they run while this rank waits for its neighbours below
     for (int ci = 0; ci < n_chunks; ++ci)
         if (!chunks[ci].needs_halo) BHR_TRY(v_chunk(ci));
     if (halo) {
-        // my rows are blurred: tell the neighbours; then pull theirs once they have said the same
+        // my rows are blurred (and, split frames, stored in the neighbours' planes): tell them; go on once they have said the same
         BHR_HIP(hipEventSynchronize(p->halo_ready));
         __atomic_store_n(mine + 0, frame, __ATOMIC_RELEASE);
         for (int side = 0; side < 2; ++side) {
-            if (!p->nb_hblur[side]) continue;
+            const bool have_nb = p->split ? p->nb_split[side].pb != nullptr : p->nb_hblur[side] != nullptr;
+            if (!have_nb) continue;
             const int nb = side == 0 ? rank - 1 : rank + 1;
             BHR_TRY(wait_counter(p->shm + (size_t)nb * BHR_TILE_SHM_WORDS, frame, "halo rows", nb));
+            if (p->split) continue;                                          // its H pass has put the rows here already
             const size_t nb_rows = p->nb_rows[side], nb_plane = (nb_rows + 2 * R) * W, my_plane = (rows + 2 * R) * W;
             const size_t src_row = side == 0 ? nb_rows : R;                  // its last / first R rows (own rows live at [R, R + rows))
             const size_t dst_row = side == 0 ? 0 : R + rows;
             for (int c = 0; c < 3; ++c)
                 BHR_HIP(hipMemcpyAsync(ctx->d_hblur + c * my_plane + dst_row * W, p->nb_hblur[side] + c * nb_plane + src_row * W,
-                                       R * W * sizeof(float), hipMemcpyDeviceToDevice, p->copy));
+                                       R * W * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         }
-        BHR_HIP(hipEventRecord(p->halo_in, p->copy));
-        BHR_HIP(hipStreamWaitEvent(ctx->stream, p->halo_in, 0));
     }
     for (int ci = 0; ci < n_chunks; ++ci)
         if (chunks[ci].needs_halo) BHR_TRY(v_chunk(ci));
-    BHR_HIP(hipEventRecord(p->landed, p->push));
-    BHR_HIP(hipStreamWaitEvent(ctx->stream, p->landed, 0));
     BHR_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    ctx->slots[ctx->active_slot].have = direct ? 0u : want;
     ctx->last_flags = (int32_t)flags;
     ctx->timing_valid = 1;
     BHR_HIP(hipStreamSynchronize(ctx->stream));
@@ -594,6 +649,27 @@ int32_t bhr_tile_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     __atomic_store_n(mine + 1, frame, __ATOMIC_RELEASE);
     for (int k = 0; k < world; ++k)
         BHR_TRY(wait_counter(p->shm + (size_t)k * BHR_TILE_SHM_WORDS + 1, frame, "end of frame", k));
+    return BHR_OK;
+}
+}  // namespace
+
+int32_t bhr_tile_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
+    if (!ctx || !cam) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_render: bad argument");
+    TilePipe *p = (TilePipe *)ctx->pipe;
+    if (!p || !p->linked) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: call bhr_tile_connect first (a failed frame breaks the link: connect again)");
+    if (flags & BHR_LENS_FLARE) return bhr_fail(BHR_ERR_INVALID, "bhr_tile_render: the lens flare needs the one-process path (bhr_group_render)");
+    if ((flags & BHR_GATHER_PEER) && !p->gather_f32) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: no f32 frame buffer was exported by rank 0");
+    if ((flags & BHR_GATHER_U8) && !p->gather_u8) return bhr_fail(BHR_ERR_STATE, "bhr_tile_render: no u8 frame buffer was exported by rank 0");
+    const int32_t rc = tile_render_linked(ctx, p, cam, flags);
+    if (rc != BHR_OK) {
+        // a failed frame leaves the counters of the ranks out of step and may leave stores / copies into the neighbours' mappings
+        // queued: drain, and refuse further frames until the ranks have connected again (later calls fail fast instead of
+        // spinning out a time-out each)
+        const std::string msg = bhr_last_error();
+        drain(ctx, p);
+        p->linked = 0;
+        return bhr_fail(rc, "%s", msg.c_str());
+    }
     return BHR_OK;
 }
 

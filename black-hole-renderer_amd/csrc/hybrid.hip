@@ -243,14 +243,11 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
         h->n_strict = 0;
         h->last_fix_slot = -1;
         // band around b_c, in r_s: measured on the fixtures and the fhd / 4k / e2e frames (tools/hybrid_sweep.py)
-        h->lo = 0.085;       // in the orbit's own b (classify): the band certified in round 3 on |pos x dir| at the 6 r_s pov,
-        h->hi = 0.36;        // [2.478, 2.898], is [b_c - 0.084, b_c + 0.357] there
-        if (const char *e = getenv("BHR_HYBRID_BAND")) {
-            double a = 0, b = 0;
-            if (sscanf(e, "%lf,%lf", &a, &b) == 2 && a >= 0 && b >= 0) { h->lo = a; h->hi = b; }
-        }
         ctx->hybrid = h;
     }
+    h->lo = 0.085;           // in the orbit's own b (classify): the band certified in round 3 on |pos x dir| at the 6 r_s pov,
+    h->hi = 0.36;            // [2.478, 2.898], is [b_c - 0.084, b_c + 0.357] there
+    if (ctx->opt.hybrid_band_set) { h->lo = ctx->opt.hybrid_band[0]; h->hi = ctx->opt.hybrid_band[1]; }   // BHR_HYBRID_BAND="lo,hi" at bhr_create, or bhr_set_option
     // the list to split: the whole row block, or the sub-list of a pipelined launch (halo bands / the rest)
     const bhr_march_part base = ctx->part;
     const int32_t *base_list = base.active ? base.h_list : ctx->h_tile_order;
@@ -306,8 +303,7 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     // Two launches.  On ONE stream the fast list waits for the last strict wave (the chip drains in between); on TWO the
     // fast tiles run on the context's low-priority second stream beside the strict ones and fill the slots they leave.
     // The bracket (start event, counter clear / end event) is an empty first / last part on the frame's own stream.
-    int streams = 2;
-    if (const char *e = getenv("BHR_HYBRID_STREAMS")) streams = atoi(e) == 1 ? 1 : 2;
+    int streams = ctx->opt.hybrid_streams;           // 2; BHR_HYBRID_STREAMS=1: both lists on the frame's stream
     if (base.active) streams = 1;                    // a pipelined row block already runs its two halves on two streams
     int32_t rc = BHR_OK;
     // The fast list's kernel carries guards: a lane that comes within a guard band of one of the algorithm's switches -- the
@@ -320,10 +316,10 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     // of a 4k tilt-25 frame by a whole disk colour: 6.5e-4 RMSE).  With tilt 0 the function is z itself, which has full
     // relative precision at the plane: no exact zeros, and the third, dependent launch would cost 17 % of the fhd frame
     // rate (guard kernel +25 us, fix kernel 55 us: one strict wave's lifetime that nothing overlaps) -- off.
-    // BHR_HYBRID_REPAIR=1 / 0 forces it on / off.
+    // BHR_HYBRID_REPAIR=1 / 0 (environment of bhr_create) forces it on / off.
     const bool aa = ctx->cfg.anti_alias != 0 && !(flags & BHR_SKIP_DIFFERENTIALS);
     bool repair = aa || ctx->cfg.disk_tilt_deg != 0.0f;
-    if (const char *e = getenv("BHR_HYBRID_REPAIR")) repair = atoi(e) != 0;
+    if (ctx->opt.hybrid_repair >= 0) repair = ctx->opt.hybrid_repair != 0;
     const int slot_k = ctx->active_slot >= 0 && ctx->active_slot < BHR_MAX_FRAME_SLOTS ? ctx->active_slot : 0;
     FixList &fx = h->fix[slot_k];
     if (repair && !fx.d_list) {

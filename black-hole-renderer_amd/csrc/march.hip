@@ -474,18 +474,38 @@ __device__ __forceinline__ void volume_segment(const BhrMarchArgs &a, Shade &sh,
     }
 }
 
-// render.py:3008-3018: background through the accumulated opacity + clamped disk layer
-__device__ __forceinline__ void write_pixel(const BhrMarchArgs &a, int pix, bool escaped, V3 esc_dir, const Shade &sh) {
+// render.py:3008-3018: background through the accumulated opacity + clamped disk layer.  (i, j) = column, local row.
+__device__ __forceinline__ void write_pixel(const BhrMarchArgs &a, int i, int j, bool escaped, V3 esc_dir, const Shade &sh) {
     V3 bg = mk(0, 0, 0);
     if (escaped) bg = sample_skybox(a.sc, normalized(esc_dir));
     float k = 1.0f - sh.alpha_total;
-    size_t o = (size_t)pix * 3;
+    size_t o = ((size_t)j * a.width + i) * 3;
     a.bg[o + 0] = bg.x * k;
     a.bg[o + 1] = bg.y * k;
     a.bg[o + 2] = bg.z * k;
-    a.disk[o + 0] = fminf(fmaxf(sh.accum.x, 0.0f), 1.0f);
-    a.disk[o + 1] = fminf(fmaxf(sh.accum.y, 0.0f), 1.0f);
-    a.disk[o + 2] = fminf(fmaxf(sh.accum.z, 0.0f), 1.0f);
+    const float dk[3] = {fminf(fmaxf(sh.accum.x, 0.0f), 1.0f), fminf(fmaxf(sh.accum.y, 0.0f), 1.0f), fminf(fmaxf(sh.accum.z, 0.0f), 1.0f)};
+    a.disk[o + 0] = dk[0];
+    a.disk[o + 1] = dk[1];
+    a.disk[o + 2] = dk[2];
+    if (a.diskp) {
+        // The disk layer once more for the split-f16 bloom (bloom.hip): every value x 2^14 cut into two f16 halves (hi =
+        // RN16, lo = RN16 of the rest: 24 significant bits between them), laid out [channel][half][32-row block][8-pixel
+        // group][row][8 pixels] -- the H pass's MFMA operand order.  The 8x8 tile of a wave is ONE 128-byte line of it per
+        // channel and half: six fully coalesced 2-byte stores per pixel instead of a 96-byte-per-lane gather and a cut in
+        // the H kernel.
+        const size_t part = (size_t)a.dp_yb * a.dp_gp * 256;
+        _Float16 *q = a.diskp + ((((size_t)(j >> 5)) * a.dp_gp + (i >> 3) + a.dp_g0) * 32 + (j & 31)) * 8 + (i & 7);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = dk[c] * 16384.0f;
+            asm volatile("" : "+v"(v));                          // one product, one conversion: the stored half and the one `lo` is
+            unsigned int hb = __builtin_bit_cast(unsigned short, (_Float16)v);   // formed against are the same bits (bloom.hip: cut2)
+            asm volatile("" : "+v"(hb));
+            const _Float16 hi = __builtin_bit_cast(_Float16, (unsigned short)hb);
+            q[(size_t)(2 * c) * part] = hi;
+            q[(size_t)(2 * c + 1) * part] = (_Float16)(v - (float)hi);
+        }
+    }
 }
 
 // Pixel -> ray (render.py:2811-2840).  Returns the unit direction; dx1/dy1 = directions through
@@ -678,8 +698,8 @@ struct Ray {
             shade_hit<DIFF, SRC>(a, sh, h.hit_x, h.hit_y, h.to_cam, h.dxx, h.dxy, h.dyx, h.dyy);
         }
     }
-    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, d, sh); }
-    __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int at) { write_pixel(a, at, done == 2, d, sh); }
+    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix % a.width, pix / a.width, done == 2, d, sh); }
+    __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int i, int j) { write_pixel(a, i, j, done == 2, d, sh); }
 };
 
 #else
@@ -914,8 +934,8 @@ struct Ray {
             shade_hit<DIFF, SRC>(a, sh, h.hit_x, h.hit_y, h.to_cam, h.dxx, h.dxy, h.dyx, h.dyy);
         }
     }
-    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix, done == 2, to3d(du, dw), sh); }
-    __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int at) { write_pixel(a, at, done == 2, to3d(du, dw), sh); }
+    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix % a.width, pix / a.width, done == 2, to3d(du, dw), sh); }
+    __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int i, int j) { write_pixel(a, i, j, done == 2, to3d(du, dw), sh); }
 };
 #endif  // BHR_MARCH_STRICT
 
@@ -1020,7 +1040,7 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
             }
             if (again) ray.step_count = 0;             // its steps are counted by the strict re-march
         }
-        if (valid2 && !again) ray.finish_at(a, j2 * a.width + i2);
+        if (valid2 && !again) ray.finish_at(a, i2, j2);
     }
     // a lane executes one step per loop iteration: its step count is the number of steps it executed (0: no ray)
     unsigned long long tot = wave_sum_u32((unsigned int)ray.step_count);
@@ -1091,7 +1111,7 @@ __global__ __launch_bounds__(256) void march_fix_kernel(BhrMarchArgs a) {
     }
     if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
     if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
-    if (valid) ray.finish_at(a, pix);
+    if (valid) ray.finish_at(a, pix % a.width, pix / a.width);
     const unsigned long long tot = wave_sum_u32((unsigned int)ray.step_count);
     if (lane == 0) atomicAdd(a.ray_steps + (size_t)(blockIdx.x & (BHR_STEP_LANES - 1)) * BHR_STEP_STRIDE, tot);
 }
@@ -1299,13 +1319,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         // hybrid = two launches over complementary tile lists (hybrid.hip); schedules and disk sources that have no
         // list form run strict
         if (mode == BHR_MATH_HYBRID && (ctx->disk_source != BHR_DISK_TEXTURE || (flags & BHR_PERSISTENT))) mode = BHR_MATH_STRICT;
-        // the frame's post-pass follows its march: exact f32 chains under strict, the bf16 x 3 matrix-core kernels (bloom.hip)
-        // under fast and hybrid where they pay (V pass from radius 16, H pass from radius 64); BHR_BLOOM_SPLIT=0 / 1 forces either for every arithmetic
-        {
-            const char *e = getenv("BHR_BLOOM_SPLIT");
-            const int forced = e ? (atoi(e) != 0 ? 1 : 0) : -1;
-            ctx->bloom_split = forced == 1 ? 2 : forced == 0 ? 0 : (mode != BHR_MATH_STRICT ? 1 : 0);   // 1: per pass, by radius (bloom.hip)
-        }
+        // (the frame's post-pass kernels were chosen by bhr_frame_begin from the same decision: api.hip)
         if (mode == BHR_MATH_HYBRID) return bhr_launch_march_hybrid(ctx, cam, flags);
         if (mode == BHR_MATH_STRICT) return bhr_launch_march_strict(ctx, cam, flags);
     }
@@ -1364,6 +1378,16 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     a.sc.n_phi = ctx->n_phi;
     a.bg = ctx->d_bg;
     a.disk = ctx->d_disk;
+    a.diskp = nullptr;
+    a.dp_yb = a.dp_gp = a.dp_g0 = 0;
+    if (ctx->bloom_split && ctx->d_pa && !(flags & BHR_SKIP_BLOOM)) {      // split-f16 post-pass: the march feeds its H pass directly
+        bhr_split_geom g;
+        bhr_split_geometry(ctx, &g);
+        a.diskp = (_Float16 *)ctx->d_pa;
+        a.dp_yb = g.YB;
+        a.dp_gp = g.GP;
+        a.dp_g0 = g.g0;
+    }
     // timed launches (bhr_render) count into their ring slot; group launches into the scalar
     const int slot = ctx->cur_slot;
     a.ray_steps = slot >= 0 ? ctx->d_steps_ring + (size_t)slot * BHR_STEP_CELL : ctx->d_ray_steps;
@@ -1412,8 +1436,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
         a.tile_order = part.d_list;
         a.n_list = part.n;
     } else {
-        const char *e = getenv("BHR_TILE_ORDER");          // "centre" (default) | "row": row-major, for A/B runs
-        if (!(e && e[0] == 'r')) {
+        if (!ctx->opt.tile_order_rows) {                    // BHR_TILE_ORDER: "centre" (default) | "row": row-major, for A/B runs
             BHR_TRY(ensure_tile_order(ctx, a.tiles_x, a.n_tiles));
             a.tile_order = ctx->d_tile_order;
         }
@@ -1433,9 +1456,7 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     } else if (!(flags & BHR_PERSISTENT) || a.dv2 || a.row_steps || part.active) {   // the persistent schedule has no Disk V2 / row-cost variant
         // waves per block: a block keeps its CU slot until its slowest wave has finished, so small
         // blocks shorten the tail; BHR_TILE_BLOCK overrides for experiments
-        int bt = 256;
-        if (const char *e = getenv("BHR_TILE_BLOCK")) bt = atoi(e);
-        if (bt != 64 && bt != 128 && bt != 256) bt = 256;
+        const int bt = ctx->opt.tile_block;               // 256; BHR_TILE_BLOCK = 64 / 128 for experiments
         const int wpb = bt / 64;
         dim3 grid((a.n_list + wpb - 1) / wpb), block(bt);
         if (ctx->disk_source == BHR_DISK_V2_VOLUME) {   // finite-thickness Disk V2: no texture footprint to track
@@ -1474,8 +1495,8 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
 #if !BHR_MARCH_STRICT
             // BHR_MIP_LDS=1: the coarse mip levels through LDS where any of them fits 44 KB (see the kernel)
             size_t staged_bytes = 0;
-            if (const char *e = getenv("BHR_MIP_LDS")) {
-                if (atoi(e) != 0 && !part.active && bt == 256) {
+            {
+                if (ctx->opt.mip_lds && !part.active && bt == 256) {
                     const int last = 3;                                     // int(clamp(lod, 0, 3)): the coarsest level ever sampled
                     for (int l = last; l >= 1; --l) {
                         if (a.sc.mip_h[last] <= 0 || a.sc.mip_w[last] <= 0) break;                  // a texture too small to have it

@@ -412,6 +412,7 @@ int32_t bhr_y4m_submit(bhr_y4m *s) {
     bhr_ctx *ctx = s->ctx;
     int32_t rc = bhr_enter_frame(ctx);       // the stream that rendered the last frame (behind its post-passes)
     hipError_t e = hipSuccess;
+    if (rc == BHR_OK) rc = bhr_ensure_outputs(ctx, BHR_OUT_F32);     // the conversion reads the f32 frame (a context that keeps only u8 rows gets it on demand)
     if (rc == BHR_OK) {
         dim3 block(32, 8), grid(((s->w >> 1) + 31) / 32, ((s->h >> 1) + 7) / 8);
         hipLaunchKernelGGL(rgb_to_yuv420_kernel, grid, block, 0, ctx->stream, ctx->d_final, s->slots[slot].dev, s->w, s->h);

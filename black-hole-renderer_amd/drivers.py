@@ -309,6 +309,9 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
                                     "-pix_fmt", "yuv420p", output_path], stdin=subprocess.PIPE)
         stream = Y4MStream(renderer, f"/proc/self/fd/{encoder.stdin.fileno()}", fps)
 
+    # the loop's consumers read the quantised rows (PNG sink) and, with a yuv420p stream, the f32 frame: the V pass of every
+    # frame stores exactly those (12 bytes per pixel less to write without a stream, 24 with the blur layer nobody reads)
+    renderer.set_outputs("u8" if stream is None else "f32+u8")
     n_r, n_phi = renderer.dtex_h, renderer.dtex_w
     factories = init_lifecycle_system(renderer, n_r, n_phi, seed=42)
     dt = disk_rotation_speed

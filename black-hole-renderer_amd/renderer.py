@@ -48,7 +48,7 @@ class HipRenderer:
                  disk_tilt=0.0, lens_flare=False, anti_alias="disabled", aa_strength=1.0,
                  disk_rotation_speed=0.1, ignore_taichi_cache=False,
                  device_index: int = 0, rows: Optional[Sequence[int]] = None, math: str = "strict",
-                 frame_slots: Optional[int] = None):
+                 frame_slots: Optional[int] = None, outputs: Optional[str] = None, options: Optional[dict] = None):
         if device not in ("hip", "gpu"):
             raise ValueError(f"HipRenderer runs on the GPU only (device={device!r}); there is no CPU path")
         # math="strict" (default): the RK4 loop in the reference's operation order with IEEE sqrt and
@@ -96,6 +96,13 @@ class HipRenderer:
                     os.environ["BHR_FRAME_SLOTS"] = saved
         self._ctx = handle
         self.frame_slots = frame_slots if frame_slots is not None else (1 if saved == "1" else 2)
+        # outputs: what a frame keeps in memory besides the bg / disk layers -- "f32" (default: what render() returns),
+        # "u8" (the quantised rows only: video loop, PNG sink, u8 gather), or several joined by "+" ("f32+blur+u8");
+        # anything not kept is produced on demand by the call that reads it.  options: {name: value} for bhr_set_option.
+        if outputs is not None:
+            self.set_outputs(outputs)
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
 
         skybox = np.ascontiguousarray(skybox, dtype=np.float32)
         disk_tex = np.ascontiguousarray(disk_tex, dtype=np.float32)
@@ -383,6 +390,20 @@ class HipRenderer:
     def sync(self) -> None:
         _lib.check(self._lib.bhr_sync(self._ctx))
 
+    def set_outputs(self, outputs: str) -> None:
+        """Layers the V pass of every later frame stores: "f32", "blur", "u8" joined by "+" (bhr_set_outputs)."""
+        bits = {"f32": _lib.OUTPUT_F32, "blur": _lib.OUTPUT_BLUR, "u8": _lib.OUTPUT_U8}
+        mask = 0
+        for part in outputs.split("+"):
+            if part not in bits:
+                raise ValueError(f"outputs: 'f32', 'blur', 'u8' joined by '+', got {outputs!r}")
+            mask |= bits[part]
+        _lib.check(self._lib.bhr_set_outputs(self._ctx, mask))
+
+    def set_option(self, name: str, value) -> None:
+        """One of the library's switches for this context (bhr_set_option; include/bhr.h lists them)."""
+        _lib.check(self._lib.bhr_set_option(self._ctx, name.encode(), float(value)))
+
     def read_layer(self, layer: int) -> np.ndarray:
         out = np.empty((self.rows, self.width, 3), dtype=np.float32)
         _lib.check(self._lib.bhr_read_layer(self._ctx, layer, _lib.fptr(out)))
@@ -410,7 +431,7 @@ class HipRenderer:
         return np.array(out[:], dtype=np.float64)
 
     def mip_lds_level(self) -> int:
-        """First mip level the last anti-aliased fast march staged in LDS (environment BHR_MIP_LDS=1), -1 if none."""
+        """First mip level the last anti-aliased fast march staged in LDS (option "mip_lds" / environment BHR_MIP_LDS=1), -1 if none."""
         return int(self._lib.bhr_mip_lds_level(self._ctx))
 
     def row_costs(self, cam_pos, fov: float, split: bool = False):

@@ -223,7 +223,8 @@ BHR_API int32_t bhr_eval_noise(bhr_ctx *ctx, const float *coords, int64_t n, int
  * in HBM until read.  Successive calls alternate between the context's two frame slots (own stream and frame
  * buffers, shared read-only scene), so frame n + 1 overlaps the tail and the post-passes of frame n; every other
  * entry point is ordered (on the device) behind the frames in flight: reads return the last frame rendered, scene
- * updates never race a march.  BHR_FRAME_SLOTS=1 in the environment of bhr_create: one frame at a time. */
+ * updates never race a march.  BHR_FRAME_SLOTS=1 in the environment of bhr_create: one frame at a time.  (Every BHR_*
+ * environment switch of the library is read once, by bhr_create.) */
 BHR_API int32_t bhr_render(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);
 /* image_field/disk_layer_field/blur_field .to_numpy() and the final image,
  * for the context's rows: (row1-row0, width, 3) f32.  Synchronises. */
@@ -236,6 +237,33 @@ BHR_API int32_t bhr_write_layer(bhr_ctx *ctx, int32_t layer, const float *in);
  * BLUR <- bloom(DISK), FINAL <- clip(BG + DISK + BLUR, 0, 1).  Whole-frame context (row blocks need their
  * neighbours' halo rows: bhr_group_render).  Asynchronous. */
 BHR_API int32_t bhr_bloom(bhr_ctx *ctx);
+/* What bhr_render keeps in memory of a frame besides the bg / disk layers.  TaichiRenderer.render() returns the f32 frame
+ * (BHR_OUTPUT_F32, the default); the video loop, the PNG sink and the u8 row-block gather only ever read the quantised
+ * rows (BHR_OUTPUT_U8: save_image's truncation fused into the V pass's epilogue, 3 bytes per pixel instead of 12);
+ * blur_field (BHR_OUTPUT_BLUR) is internal to the reference's render().  A layer that was not kept is produced on demand
+ * by whichever call needs it (bhr_read_layer, bhr_read_final_u8, the sinks): the frame's V pass runs again for it, same
+ * kernels, same bits.  mask: any non-empty combination. */
+#define BHR_OUTPUT_F32 1u
+#define BHR_OUTPUT_BLUR 2u
+#define BHR_OUTPUT_U8 4u
+BHR_API int32_t bhr_set_outputs(bhr_ctx *ctx, uint32_t mask);
+/* The library's switches.  Each has an environment variable that bhr_create reads ONCE (no entry point calls getenv
+ * afterwards) and can be changed per context later with this call -- what tests and A/B tools use:
+ *   "bloom_split"     BHR_BLOOM_SPLIT     -1 post-pass by arithmetic (exact f32 under strict, split f16 under fast / hybrid), 0 / 1 force
+ *   "bloom_tiles"     BHR_BLOOM_TILES     0 output tiles per wave of the split post-pass by launch size, 1..8 force (A/B runs)
+ *   "hybrid_repair"   BHR_HYBRID_REPAIR   -1 guards + strict fix list by view (anti-aliased or tilted), 0 / 1 force
+ *   "hybrid_band_lo" / "hybrid_band_hi" / "hybrid_band_default"   BHR_HYBRID_BAND="lo,hi"   strict band around b_c, in r_s
+ *   "hybrid_streams"  BHR_HYBRID_STREAMS  2 the two lists of a hybrid march on two streams, 1 on one
+ *   "mip_lds"         BHR_MIP_LDS         1 anti-aliased fast frames stage the coarse mip levels in LDS
+ *   "tile_order_rows" BHR_TILE_ORDER=row  1 row-major march launch order
+ *   "group_threads"   BHR_GROUP_THREADS   -1 one submitting thread per tile where the tiles sit on distinct devices, 0 / 1 force
+ *   "group_schedule"  BHR_GROUP_SCHEDULE  -1 by flags / device layout, 0 serial, 1 pipelined (explicit flags still win)
+ * (bhr_create only: BHR_FRAME_SLOTS, BHR_TILE_BLOCK, BHR_AUX_STREAMS, BHR_STREAM_PAD.) */
+BHR_API int32_t bhr_set_option(bhr_ctx *ctx, const char *name, double value);
+/* Diagnostics (tests): the split-f16 post-pass's packed intermediates of the last frame as raw bytes -- which = 0 the H pass's
+ * input (csrc/bloom.hip: pa), 1 its output / the V pass's input (pb) -- and the layout's geometry: geom[10] = {NT, n_tx, WP, YB,
+ * GP, g0, t_first, n_ty, pbr, GR}.  out == NULL or bytes == 0: geometry only.  Synchronises. */
+BHR_API int32_t bhr_debug_read(bhr_ctx *ctx, int32_t which, void *out, int64_t bytes, int32_t *geom);
 /* TaichiRenderer._apply_lens_flare(final, disk) (render.py:3925-4028) on the device, standalone:
  * FINAL <- clip(FINAL + flare(DISK), 0, 1) for a whole-frame context.  bhr_render / bhr_group_render
  * with BHR_LENS_FLARE run the same kernels after the combine.  Asynchronous. */
@@ -264,15 +292,15 @@ BHR_API int32_t bhr_timing_reset(bhr_ctx *ctx);
 /* The last n timed bhr_render calls, oldest first: out[3 k .. 3 k + 2] = march start, march end, frame end of frame k in
  * milliseconds after the oldest frame's march start (HIP events on the frame slots' streams).  Synchronises. */
 BHR_API int32_t bhr_timing_dump(bhr_ctx *ctx, float *out, int32_t n);
+/* BHR_MIP_LDS=1 (environment of bhr_create): anti-aliased frames of the fast arithmetic stage the coarse levels of the disk
+ * texture's mip stack in LDS -- as many of levels 3, 2, 1 as fit 44 KB -- and sample them from there (BASELINE.json's "mipmap
+ * levels staged through LDS"; not the default: DESIGN.md section 4).  Returns the first staged level of the last such march,
+ * -1 if it staged none (switch off, another arithmetic, or a texture whose level 3 alone exceeds the budget). */
+BHR_API int32_t bhr_mip_lds_level(bhr_ctx *ctx);
 /* Cost of each band of 8 rows in the last bhr_render(..., BHR_ROW_COSTS), in ray-step units: the ray-steps marched
  * plus 320 per wave-wide shading pass.  n = ceil(rows / 8) values.
  * The step count of a ray depends on the camera, the step size and the escape radius only -- not on the
  * textures -- so a small probe frame gives the cost profile of a large one (multigpu.balanced_row_blocks). */
-/* BHR_MIP_LDS=1 (environment): anti-aliased frames of the fast arithmetic stage the coarse levels of the disk texture's mip
- * stack in LDS -- as many of levels 3, 2, 1 as fit 44 KB -- and sample them from there (BASELINE.json's "mipmap levels staged
- * through LDS"; not the default: DESIGN.md section 4).  Returns the first staged level of the last such march, -1 if it staged
- * none (switch off, another arithmetic, or a texture whose level 3 alone exceeds the budget). */
-BHR_API int32_t bhr_mip_lds_level(bhr_ctx *ctx);
 BHR_API int32_t bhr_get_row_costs(bhr_ctx *ctx, uint64_t *out, int32_t n);
 /* The same profile split by the arithmetic that took the steps: a math_mode 2 (hybrid) frame marches its tiles near the
  * photon ring with the strict kernel, ~2.2x the cost per step of the fast one -- row blocks of hybrid frames are balanced

@@ -1,7 +1,9 @@
-"""The post-pass on the bf16 matrix cores (csrc/bloom.hip: f32 operands cut into three bf16 parts, six MFMA products per
-chunk of 16 taps), which the fast and hybrid arithmetic use from bloom radius 64 up (4k, 8k): against the exact f32
-kernels on the same layers, against the oracle's `_bloom_kernel` restatement (render.py:3022-3114), through properties at
-8k, and that row blocks give the same bits as one context (chunks are aligned to global multiples of 16)."""
+"""The post-pass on the f16 matrix cores (csrc/bloom.hip: every f32 operand cut into two f16 halves, three MFMA products
+per chunk of 16 taps; operands pre-cut and in fragment order -- the march writes the H pass's input, the H pass the V
+pass's), which the fast and hybrid arithmetic use at every size: against the exact f32 kernels on the same layers, against
+the oracle's `_bloom_kernel` restatement (render.py:3022-3114), through properties at 8k, that row blocks give the same
+bits as one context (chunks are aligned to global multiples of 16; halo rows stored by the neighbours' H passes, frame
+rows by the V passes, no copies), and that the V pass stores only what was asked for -- the rest on demand, same bits."""
 import numpy as np
 import pytest
 
@@ -14,52 +16,60 @@ CAM, FOV = [6.0, 0.0, 0.5], 90.0
 
 
 def _both_blooms(r, disk, bg):
-    """(blur, final) of the layers through the bf16 kernels and through the exact f32 kernels of one context"""
+    """(blur, final) of the layers through the split-f16 kernels and through the exact f32 kernels of one context"""
     from bhr_amd import _lib
     out = {}
-    for math in ("fast", "strict"):                        # the march of a frame picks the post-pass that follows it
-        r.render_async(CAM, FOV, math=math, skip_bloom=True)
+    for split in (1, 0):
+        r.set_option("bloom_split", split)
+        r.render_async(CAM, FOV, skip_bloom=True)
         r.write_layer(_lib.LAYER_DISK, disk)
         r.write_layer(_lib.LAYER_BG, bg)
         r.bloom_only()
-        out[math] = (r.read_layer(_lib.LAYER_BLUR), r.read_layer(_lib.LAYER_FINAL))
-    return out["fast"], out["strict"]
+        out[split] = (r.read_layer(_lib.LAYER_BLUR), r.read_layer(_lib.LAYER_FINAL))
+    r.set_option("bloom_split", -1)
+    return out[1], out[0]
 
 
-def test_4k_split_bloom_against_exact_kernels_and_oracle(oracle, hip_lib):
+@pytest.mark.parametrize("size", [(1920, 1080), (3840, 2160)])
+def test_split_bloom_against_exact_kernels_and_oracle(size, oracle, hip_lib):
     from bhr_amd import HipRenderer, _lib
-    W, H = 3840, 2160
+    W, H = size
     sky, tex = scenes.analytic_skybox(128, 256), scenes.noisy_disk(256, 1024)
-    r = HipRenderer(W, H, sky, tex, math="fast", frame_slots=1, **KW)
+    r = HipRenderer(W, H, sky, tex, math="fast", frame_slots=1, outputs="f32+blur", **KW)
     r.render_async(CAM, FOV)
     disk, bg = r.read_layer(_lib.LAYER_DISK), r.read_layer(_lib.LAYER_BG)
+    blur_frame, final_frame = r.read_layer(_lib.LAYER_BLUR), r.read_layer(_lib.LAYER_FINAL)
     assert disk.max() > 0.3
     (blur_s, final_s), (blur_x, final_x) = _both_blooms(r, disk, bg)
     r.close()
+    # the frame's own post-pass (H input written by the march kernel) == the stand-alone pass (H input packed from the layer)
+    np.testing.assert_array_equal(blur_frame, blur_s)
+    np.testing.assert_array_equal(final_frame, final_s)
     assert not np.array_equal(blur_s, blur_x)              # two different kernels did run
     d = np.abs(blur_s - blur_x)
     e = np.sqrt(np.mean(d.astype(np.float64) ** 2, axis=(0, 1)))
-    print(f"\n[bloom split] 4k blur layer, bf16 x 3 against exact f32: max {d.max():.3g}, per-channel RMSE {e}")
+    print(f"\n[bloom split] {W}x{H} blur layer, f16 x 2 against exact f32: max {d.max():.3g}, per-channel RMSE {e}")
     assert d.max() <= 3e-6 and (e <= 5e-7).all(), (d.max(), e)
     assert np.abs(final_s - final_x).max() <= 3e-6
     ora = oracle.OracleRenderer(W, H, sky, tex, **KW)
     ref, _ = ora.bloom(disk.transpose(1, 0, 2))
     ref = ref.transpose(1, 0, 2)
-    for name, got in (("bf16 x 3", blur_s), ("exact f32", blur_x)):
+    for name, got in (("f16 x 2", blur_s), ("exact f32", blur_x)):
         dd = np.abs(got - ref)
         ee = np.sqrt(np.mean(dd.astype(np.float64) ** 2, axis=(0, 1)))
-        print(f"[bloom split] 4k blur layer, {name} against the oracle: max {dd.max():.3g}, per-channel RMSE {ee}")
+        print(f"[bloom split] {W}x{H} blur layer, {name} against the oracle: max {dd.max():.3g}, per-channel RMSE {ee}")
         assert dd.max() <= 5e-6 and (ee <= 1e-6).all(), (name, dd.max(), ee)
 
 
 def test_8k_split_bloom_properties(hip_lib):
-    """radius 153, two stacked tiles per wave: a constant layer is a fixed point (edges included), halving is exact,
-    the operator commutes with the left-right flip up to rounding, outputs are convex combinations of inputs"""
+    """radius 153, eight stacked tiles per wave: a constant layer is a fixed point (edges included), the operator commutes
+    with the left-right flip up to rounding, outputs are convex combinations of inputs, a faint floor keeps its relative
+    accuracy (every half stays a normal f16 down to 4e-9)"""
     from bhr_amd import HipRenderer, _lib
     W, H = 7680, 4320
     r = HipRenderer(W, H, np.zeros((16, 32, 3), np.float32), np.zeros((32, 64, 4), np.float32), math="fast", frame_slots=1,
                     **dict(KW, step_size=0.5))
-    r.render_async(CAM, FOV, skip_bloom=True)              # a fast frame: the bf16 post-pass is the context's
+    r.render_async(CAM, FOV, skip_bloom=True)
     r.write_layer(_lib.LAYER_BG, np.zeros((H, W, 3), np.float32))
 
     def bloom(x):
@@ -79,131 +89,107 @@ def test_8k_split_bloom_properties(hip_lib):
     x[:, -2:] = 0.7
     bx = bloom(x)
     assert bx.max() > 0.05 and np.isfinite(bx).all()
-    np.testing.assert_array_equal(bloom(0.5 * x), 0.5 * bx)                             # exact: every part halves
     np.testing.assert_allclose(bloom(np.ascontiguousarray(x[:, ::-1])), bx[:, ::-1], rtol=2e-5, atol=3e-6)
     assert bx.max() <= x.max() + 3e-6 and bx.min() >= -1e-9
+    # a frame of faint values only: 1e-6 .. 1e-4 (far below the 6e-5 where an unscaled f16 would go subnormal)
+    faint = (rng.random((H, W, 3), dtype=np.float32) * 1e-4 + 1e-6).astype(np.float32)
+    r.set_option("bloom_split", 0)
+    exact = bloom(faint)
+    r.set_option("bloom_split", 1)
+    got = bloom(faint)
     r.close()
+    rel = np.abs(got - exact) / exact
+    assert rel.max() <= 2e-5, rel.max()
 
 
 def test_split_bloom_row_blocks_equal_one_context_bit_for_bit(hip_lib):
-    """4k fast frame in 5 uneven row blocks (cuts not multiples of 16 or 32) == one context, every bit of the gathered
-    frame: an output's operands meet the same MFMA slots whatever the tiling"""
+    """4k fast frame in 5 uneven row blocks (cuts not multiples of 4, 16 or 32) == one context, every bit of the gathered
+    frame in every gather mode: an output's operands meet the same MFMA slots whatever the tiling; the halo rows arrive by
+    the neighbours' H passes, the frame rows by the V passes' epilogues"""
     from bhr_amd import HipRenderer, multigpu
     W, H = 3840, 2160
     sky, tex = scenes.analytic_skybox(128, 256), scenes.noisy_disk(256, 1024)
     full = HipRenderer(W, H, sky, tex, math="fast", frame_slots=1, **KW)
     ref = full.render(CAM, FOV)
+    ref_u8 = full.read_final_u8()
     full.close()
     cuts = [0, 401, 918, 1247, 1795, H]
     tiles = [HipRenderer(W, H, sky, tex, rows=(cuts[k], cuts[k + 1]), math="fast", frame_slots=1, **KW) for k in range(5)]
     for sched in ("serial", "pipelined"):
         multigpu.group_render(tiles, CAM, FOV, gather="peer", schedule=sched)
         np.testing.assert_array_equal(multigpu.read_gathered(tiles), ref)
+        multigpu.group_render(tiles, CAM, FOV, gather="peer_u8", schedule=sched)
+        np.testing.assert_array_equal(multigpu.read_gathered_u8(tiles), ref_u8)
+        np.testing.assert_array_equal(multigpu.group_render(tiles, CAM, FOV, gather="host", schedule=sched), ref)
+    # after a direct gather a tile's own buffers hold nothing of the frame: reading one produces it on demand
+    multigpu.group_render(tiles, CAM, FOV, gather="peer_u8")
+    from bhr_amd import _lib
+    np.testing.assert_array_equal(tiles[2].read_layer(_lib.LAYER_FINAL), ref[cuts[2]:cuts[3]])
     for t in tiles:
         t.close()
 
 
-def test_fhd_fast_keeps_the_f32_post_pass_and_odd_widths_fall_back(hip_lib, monkeypatch):
-    """A small frame (radius 6 < 64, like fhd's 38): the fast arithmetic keeps the f32 post-pass; a width that is not a multiple of 16 keeps it even
-    when the bf16 pass is forced on by the environment switch (the H kernel's chunks must tile a row)."""
+def test_strict_frames_keep_the_exact_post_pass_and_the_switch_forces_either(hip_lib):
+    """strict frames run the exact f32 kernels (bit-identical to round 3's), fast frames the split ones; the option forces
+    either for any arithmetic"""
     from bhr_amd import HipRenderer, _lib
     s = scenes.SCENES["default"]
     sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
-    for (w, h), force in (((s["width"], s["height"]), False), ((200, 120), True)):
-        if force:
-            monkeypatch.setenv("BHR_BLOOM_SPLIT", "1")
-        a = HipRenderer(w, h, sky, tex, math="fast", **s["kw"])
-        b = HipRenderer(w, h, sky, tex, math="strict", **s["kw"])
+    for (w, h) in ((s["width"], s["height"]), (203, 121)):           # any width, any height
+        a = HipRenderer(w, h, sky, tex, math="strict", frame_slots=1, **s["kw"])
         a.render_async([6, 0, 0.5], 90)
-        disk, bg = a.read_layer(_lib.LAYER_DISK), a.read_layer(_lib.LAYER_BG)
-        monkeypatch.delenv("BHR_BLOOM_SPLIT", raising=False)
-        b.render_async([6, 0, 0.5], 90, skip_bloom=True)
-        b.write_layer(_lib.LAYER_DISK, disk)
-        b.write_layer(_lib.LAYER_BG, bg)
-        b.bloom_only()
-        np.testing.assert_array_equal(a.read_layer(_lib.LAYER_BLUR), b.read_layer(_lib.LAYER_BLUR))
+        disk, bg, blur_strict = a.read_layer(_lib.LAYER_DISK), a.read_layer(_lib.LAYER_BG), a.read_layer(_lib.LAYER_BLUR)
+        (blur_s, _), (blur_x, _) = _both_blooms(a, disk, bg)
+        np.testing.assert_array_equal(blur_strict, blur_x)
+        assert not np.array_equal(blur_s, blur_x) and np.abs(blur_s - blur_x).max() <= 3e-6
+        a.set_option("bloom_split", 1)
+        a.render_async([6, 0, 0.5], 90)
+        np.testing.assert_array_equal(a.read_layer(_lib.LAYER_BLUR), blur_s)      # a strict march feeding the split post-pass
         a.close()
-        b.close()
 
 
-def test_split_bloom_is_exactly_scale_invariant_over_the_f32_range(hip_lib, monkeypatch):
-    """Cutting an f32 value into three bf16 parts commutes with powers of two, and so does every product and sum of the
-    kernels: bloom(2^k x) == 2^k bloom(x) bit for bit from 2^-60 to 2^40 (no part under- or overflows anywhere near the
-    values a frame holds); a layer of HDR spikes on a faint floor stays within 3e-6 of the exact kernels RELATIVE to the
-    local result."""
+def test_frames_store_what_was_asked_for_and_the_rest_on_demand(hip_lib):
+    """outputs="u8": the V pass writes 3 bytes per pixel and nothing else; the f32 frame and the blur layer are produced by the
+    call that reads them -- the same bits a context that stores everything holds.  With the lens flare the u8 rows follow the
+    flared f32 frame."""
     from bhr_amd import HipRenderer, _lib
-    monkeypatch.setenv("BHR_BLOOM_SPLIT", "1")
     W, H = 1280, 720
-    r = HipRenderer(W, H, np.zeros((16, 32, 3), np.float32), np.zeros((32, 64, 4), np.float32), math="fast", frame_slots=1,
-                    **dict(KW, step_size=0.5))
-    r.render_async(CAM, FOV, skip_bloom=True)
-    r.write_layer(_lib.LAYER_BG, np.zeros((H, W, 3), np.float32))
-
-    def bloom(x):
-        r.write_layer(_lib.LAYER_DISK, x)
-        r.bloom_only()
-        return r.read_layer(_lib.LAYER_BLUR)
-
-    rng = np.random.default_rng(3)
-    x = (rng.random((H, W, 3), dtype=np.float32) * 1e-3).astype(np.float32)
-    ys, xs = rng.integers(0, H, 400), rng.integers(0, W, 400)
-    x[ys, xs] = rng.random((400, 3), dtype=np.float32) * 50.0
-    base = bloom(x)
-    assert np.isfinite(base).all() and base.max() > 0.01
-    for k in (-60, -20, 14, 40):
-        sc = np.float32(2.0) ** k
-        np.testing.assert_array_equal(bloom(x * sc), base * sc, err_msg=f"2^{k}")
-    monkeypatch.setenv("BHR_BLOOM_SPLIT", "0")
-    r.render_async(CAM, FOV, skip_bloom=True, math="strict")
-    exact = bloom(x)
-    r.close()
-    assert not np.array_equal(exact, base)
-    rel = np.abs(base - exact) / np.maximum(exact, 1e-12)
-    assert rel.max() <= 3e-6, rel.max()
-
-
-def test_fhd_fast_frames_take_the_bf16_v_pass_only(hip_lib):
-    """1920x1080 (radius 38: between the V pass's threshold of 16 and the H pass's 64): a fast frame's post-pass differs
-    from the exact kernels' by the bf16 V pass alone -- within 3e-6 -- and equals an f32 H pass followed by a forced bf16 V."""
-    from bhr_amd import HipRenderer, _lib
-    sky, tex = scenes.analytic_skybox(128, 256), scenes.noisy_disk(256, 1024)
-    r = HipRenderer(1920, 1080, sky, tex, math="fast", frame_slots=1, **KW)
-    r.render_async(CAM, FOV)
-    disk, bg = r.read_layer(_lib.LAYER_DISK), r.read_layer(_lib.LAYER_BG)
-    (blur_s, final_s), (blur_x, final_x) = _both_blooms(r, disk, bg)
-    r.close()
-    d = np.abs(blur_s - blur_x)
-    assert 0 < d.max() <= 3e-6 and np.abs(final_s - final_x).max() <= 3e-6, d.max()
+    sky, tex = scenes.analytic_skybox(128, 256), scenes.noisy_disk(128, 512)
+    for math in ("fast", "strict"):
+        for flare in (False, True):
+            kw = dict(KW, disk_tilt=20.0, lens_flare=flare)
+            everything = HipRenderer(W, H, sky, tex, math=math, frame_slots=1, outputs="f32+blur+u8", **kw)
+            everything.render_async(CAM, FOV)
+            want = (everything.read_layer(_lib.LAYER_FINAL), everything.read_layer(_lib.LAYER_BLUR), everything.read_final_u8())
+            everything.close()
+            np.testing.assert_array_equal(want[2], (np.clip(want[0], 0, 1) * 255).astype(np.uint8))
+            for outputs in ("u8", "f32", "blur"):
+                lean = HipRenderer(W, H, sky, tex, math=math, frame_slots=2, outputs=outputs, **kw)
+                for order in ((2, 0, 1), (1, 0, 2), (0, 2, 1)):
+                    lean.render_async(CAM, FOV)
+                    for what in order:
+                        got = lean.read_final_u8() if what == 2 else lean.read_layer(_lib.LAYER_FINAL if what == 0 else _lib.LAYER_BLUR)
+                        np.testing.assert_array_equal(got, want[what], err_msg=f"{math} flare={flare} outputs={outputs} order={order} what={what}")
+                lean.close()
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_random_row_blocks_and_sizes_split_bloom(seed, hip_lib, monkeypatch):
-    """Small frames with the bf16 post-pass forced on (radius 6 ... 25, one and two tiles per wave), cut into 2-6 random
-    row blocks, some thinner than the radius (multi-hop halo): the gathered frame of both schedules == one context bit for
-    bit, and the one-context frame sits within 3e-6 of the exact f32 kernels."""
+def test_random_row_blocks_and_sizes_split_bloom(seed, hip_lib):
+    """Small frames through the split post-pass (radius 4 ... 25), cut into 2-6 random row blocks, some thinner than the
+    radius (multi-hop halo), any width and height: the gathered frame of both schedules == one context bit for bit, and the
+    one-context frame sits within 3e-6 of the exact f32 kernels."""
     from bhr_amd import HipRenderer, multigpu
     rng = np.random.default_rng(100 + seed)
-    # widths that are multiples of 16 but not of 32 or 128 leave partial column strips / output tiles at the right edge
-    W, H = [(640, 400), (320, 208), (960, 540), (1280, 720), (400, 205), (1008, 567)][seed % 6]      # heights: any
-    monkeypatch.setenv("BHR_BLOOM_SPLIT", "1")
-    if seed % 2:
-        monkeypatch.setenv("BHR_BLOOM_H", "bf16x2")
-        monkeypatch.setenv("BHR_BLOOM_V", "bf16x2")
+    W, H = [(640, 400), (320, 208), (960, 540), (1280, 720), (403, 205), (1001, 567)][seed % 6]
     sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()
     kw = dict(KW, disk_tilt=float(rng.uniform(-30, 30)))
     cam = [float(rng.uniform(4, 9)), float(rng.uniform(-2, 2)), float(rng.uniform(-1.5, 1.5))]
     full = HipRenderer(W, H, sky, tex, math="fast", frame_slots=1, **kw)
     ref = full.render(cam, FOV)
-    monkeypatch.setenv("BHR_BLOOM_SPLIT", "0")
-    monkeypatch.delenv("BHR_BLOOM_H", raising=False)
-    monkeypatch.delenv("BHR_BLOOM_V", raising=False)
+    full.set_option("bloom_split", 0)
     exact = full.render(cam, FOV)
     full.close()
     assert not np.array_equal(ref, exact) and np.abs(ref - exact).max() <= 3e-6
-    monkeypatch.setenv("BHR_BLOOM_SPLIT", "1")
-    if seed % 2:
-        monkeypatch.setenv("BHR_BLOOM_H", "bf16x2")
-        monkeypatch.setenv("BHR_BLOOM_V", "bf16x2")
     n = int(rng.integers(2, 7))
     inner = np.sort(rng.choice(np.arange(3, H - 3), size=n - 1, replace=False))
     inner = [int(c) for c in inner]

@@ -83,9 +83,9 @@ def test_threaded_submission_gives_the_same_frame(hip_lib, monkeypatch):
     device (BHR_GROUP_THREADS=1) so that the path runs on the test box: the frame must not change."""
     from bhr_amd import multigpu
     s, tiles, full = _tiles([0, 50, 54, 120, 180], [0, 0, 0, 0])
-    monkeypatch.setenv("BHR_GROUP_THREADS", "0")
+    tiles[0].set_option("group_threads", 0)          # the group's switches are the first tile's (BHR_GROUP_THREADS at bhr_create)
     want = multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="host")
-    monkeypatch.setenv("BHR_GROUP_THREADS", "1")
+    tiles[0].set_option("group_threads", 1)
     for _ in range(5):
         np.testing.assert_array_equal(multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="host"), want)
         multigpu.group_render(tiles, s["cam_pos"], s["fov"], gather="peer")
