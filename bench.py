@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--persistent", action="store_true", help="A/B: persistent waves + queue refill instead of the tile schedule")
     ap.add_argument("--no-other-math", action="store_true", help="skip the informational A/B leg (profiling)")
+    ap.add_argument("--no-config2", action="store_true", help="skip the informational 4k leg (BASELINE.json configs[2])")
     ap.add_argument("--frame-slots", type=int, default=None, choices=[1, 2],
                     help="frames in flight per context (default 2: successive frames overlap on two streams)")
     ap.add_argument("--strong", action="store_true",
@@ -68,7 +69,7 @@ def parse():
     ap.add_argument("--tile-leg-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: run tile_leg on this many devices, print its dict
     ap.add_argument("--tile-tail-tiles", type=int, default=8,
                     help="at N = 1: also time ONE tile of this many alone on the device (row-block leg's single-tile budget); 0 skips it")
-    ap.add_argument("--video-frames", type=int, default=300,
+    ap.add_argument("--video-frames", type=int, default=1800,
                     help="informational leg at N = 1: frames of the video driver's loop (configs[4]: orbit, lifecycle texture "
                          "every frame, PNG files written); 0 skips it")
     ap.add_argument("--math", default="hybrid", choices=["fast", "strict", "hybrid"],
@@ -145,6 +146,7 @@ def tile_leg(wl, n, frames, math=None, warmup=3):
         for _ in range(frames):
             multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer_u8")   # synchronises every tile's stream
         el = time.perf_counter() - t0
+        multigpu.group_render(tiles, wl["cam_pos"], wl["fov"], gather="peer_u8", time_march=True)    # un-timed: per-tile march durations
         cs = [t.counters() for t in tiles]
         steps = sum(c["ray_steps"] for c in cs)
         return {"metric": "Mray-steps/s", "value": steps * frames / el / 1e6, "unit": "Mray-steps/s", "scaling": "strong",
@@ -153,7 +155,8 @@ def tile_leg(wl, n, frames, math=None, warmup=3):
                 "workload": f"{wl['width']}x{wl['height']} default scene, step_size {wl['step_size']}, one frame in {n} row blocks",
                 "row_blocks": [list(b) for b in blocks],
                 "tile_ms": {"march": [round(c["march_ms"], 3) for c in cs], "frame": [round(c["frame_ms"], 3) for c in cs]},
-                "exchange": "bloom halo rows + gather of the quantised u8 rows (what save_image writes) onto device 0 with hipMemcpyPeerAsync, no collective",
+                "exchange": "bloom halo rows stored by every tile's H pass straight into its neighbours' planes, quantised u8 rows (what save_image writes) "
+                            "stored by its V pass straight into the frame buffer on device 0 (peer-mapped memory over xGMI, no copy stage, no collective)",
                 "driven_by": "rank 0 drives all devices in one process (bhr_group_render); the other ranks wait at a host barrier",
                 "scene": note}
     finally:
@@ -187,6 +190,8 @@ def tile_leg_per_rank(wl, rank, world, local_rank, dist, frames, math=None, warm
     only its own GPU.  Every rank calls this; rank 0 gets the result, the others None."""
     from bhr_amd import distributed as D, multigpu, workloads
     blocks = workloads.plan_blocks(wl, world, local_rank, math=math)
+    import pickle
+    blocks = pickle.loads(D.host_all_gather_bytes(pickle.dumps(blocks), dist)[0])        # the cut is refined by timings: every rank takes rank 0's
     tile, dims = workloads.make_tile(wl, blocks[rank], local_rank, math=math)
     shm = f"bhr_tiles_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
     link = multigpu.TileLink(tile, rank, world, lambda b: D.host_all_gather_bytes(b, dist), shm, gather="peer_u8")
@@ -198,8 +203,8 @@ def tile_leg_per_rank(wl, rank, world, local_rank, dist, frames, math=None, warm
         for _ in range(frames):
             link.render(wl["cam_pos"], wl["fov"])
         el = time.perf_counter() - t0
+        link.render(wl["cam_pos"], wl["fov"], time_march=True)       # un-timed: per-tile march durations
         c = tile.counters()
-        import pickle
         cs = [pickle.loads(b) for b in D.host_all_gather_bytes(pickle.dumps((c["ray_steps"], c["march_ms"], c["frame_ms"], el)), dist)]
         if rank != 0:
             return None
@@ -209,8 +214,8 @@ def tile_leg_per_rank(wl, rank, world, local_rank, dist, frames, math=None, warm
                 "workload": f"{wl['width']}x{wl['height']} default scene, step_size {wl['step_size']}, one frame in {world} row blocks",
                 "row_blocks": [list(b) for b in blocks],
                 "tile_ms": {"march": [round(x[1], 3) for x in cs], "frame": [round(x[2], 3) for x in cs]},
-                "exchange": "bloom halo rows pulled from the neighbours' IPC-shared planes, quantised rows pushed into rank 0's IPC-shared "
-                            "frame buffer (peer copies over xGMI, no collective)",
+                "exchange": "bloom halo rows stored by the H pass into the neighbours' IPC-shared planes, quantised rows stored by the V pass into "
+                            "rank 0's IPC-shared frame buffer (peer memory over xGMI, no copy stage, no collective)",
                 "driven_by": "one process per tile (bhr_tile_render): pipelined schedule, shared-memory counters between the ranks",
                 "scene": f"{world} row blocks {blocks} cut by cost, every rank its own scene copy (lifecycle disk texture {dims[0]}x{dims[1]})"}
     finally:
@@ -245,32 +250,35 @@ def tile_tail_leg(wl, n_tiles=8, math=None, reps=8, verbose=False, schedules=("s
                 for _ in range(max(reps // 2, 2)):
                     multigpu.group_render(tiles, cam, fov, gather=g, schedule=sched)
                 out[f"all_tiles_one_device_ms_{sched}_{g}"] = (time.perf_counter() - t0) / max(reps // 2, 2) * 1e3
-        # march alone, per tile (its own kernel bracket, nothing else on the device)
-        march_alone = []
-        for t in tiles:
-            for _ in range(2):
-                t.render_async(cam, fov, skip_bloom=True)
-            ms = []
-            for _ in range(reps):
-                t.render_async(cam, fov, skip_bloom=True)
-                ms.append(t.counters()["march_ms"])
-            march_alone.append(float(np.median(ms)))
-        multigpu.group_render(tiles, cam, fov, gather=gathers[0], schedule=schedules[0])      # every tile's buffers current again
+        # Per tile, INTERLEAVED: its march alone (own kernel bracket, nothing else on the device, no post-pass: the march kernel
+        # then skips the packed copy it writes for the H pass) and the tile end to end under every schedule / gather, one of
+        # each per repetition -- the chip's clock drifts by a few per cent over the seconds this leg runs, and timing all the
+        # marches first made the later tiles' tails look 0.07 ms longer than they are.
         for k, t in enumerate(tiles):
             live = [1 if q == k else 0 for q in range(n_tiles)]
-            row = {"tile": k, "rows": list(blocks[k]), "march_alone_ms": march_alone[k]}
-            for sched in schedules:
-                for g in gathers:
-                    for _ in range(2):
-                        multigpu.group_render(tiles, cam, fov, gather=g, schedule=sched, live=live)
-                    e2e, wall = [], []
-                    for _ in range(reps):
-                        t0 = time.perf_counter()
-                        multigpu.group_render(tiles, cam, fov, gather=g, schedule=sched, live=live)
-                        wall.append((time.perf_counter() - t0) * 1e3)
-                        e2e.append(t.counters()["frame_ms"])
-                    row[f"e2e_ms_{sched}_{g}"] = float(np.median(e2e))
-                    row[f"wall_ms_{sched}_{g}"] = float(np.median(wall))
+            combos = [(sched, g) for sched in schedules for g in gathers]
+            for sched, g in combos:
+                for _ in range(2):
+                    multigpu.group_render(tiles, cam, fov, gather=g, schedule=sched, live=live)
+            for _ in range(2):
+                t.render_async(cam, fov, skip_bloom=True)
+            alone, e2e, wall = [], {c: [] for c in combos}, {c: [] for c in combos}
+            for _ in range(reps):
+                t.render_async(cam, fov, skip_bloom=True)
+                alone.append(t.counters()["march_ms"])
+                for sched, g in combos:
+                    t0 = time.perf_counter()
+                    multigpu.group_render(tiles, cam, fov, gather=g, schedule=sched, live=live)
+                    wall[(sched, g)].append((time.perf_counter() - t0) * 1e3)
+                    e2e[(sched, g)].append(t.counters()["frame_ms"])
+            row = {"tile": k, "rows": list(blocks[k]), "march_alone_ms": float(np.median(alone))}
+            for sched, g in combos:
+                row[f"e2e_ms_{sched}_{g}"] = float(np.median(e2e[(sched, g)]))
+                row[f"wall_ms_{sched}_{g}"] = float(np.median(wall[(sched, g)]))
+            # the march INSIDE the tile's frame (BHR_GROUP_TIME_MARCH brackets it with two more event records)
+            for _ in range(2):
+                multigpu.group_render(tiles, cam, fov, gather=gathers[0], schedule=schedules[0], live=live, time_march=True)
+            row["march_in_frame_ms"] = t.counters()["march_ms"]
             out["per_tile"].append(row)
             if verbose:
                 print(row, flush=True)
@@ -282,10 +290,12 @@ def tile_tail_leg(wl, n_tiles=8, math=None, reps=8, verbose=False, schedules=("s
         out["tile_march_alone_ms"] = slow["march_alone_ms"]
         out["tile_tail_ms"] = slow[key] - slow["march_alone_ms"]
         out["tile_tail_frac"] = out["tile_tail_ms"] / slow[key]
-        # what the copies of one tile would take on a 153 GB/s xGMI link (on this device they are HBM to HBM)
+        # what a tile's kernels store into peer memory on N devices (local HBM here): the rows each neighbour's V pass reaches
+        # (bloom radius padded to 16-tap chunks, both f16 halves of three channels), and its own quantised rows
         W, R = wl["width"], int(wl["width"] * 0.02)
         rows = max(b[1] - b[0] for b in blocks)
-        out["xgmi_copy_ms"] = {"halo_pull": 3 * R * W * 4 / 153e9 * 1e3, "u8_rows": rows * W * 3 / 153e9 * 1e3, "f32_rows": rows * W * 12 / 153e9 * 1e3}
+        reach = 16 * ((R + 15) // 16) + 32
+        out["peer_store_mb"] = {"halo_rows_per_neighbour": reach * W * 12 / 1e6, "u8_rows": rows * W * 3 / 1e6}
         out["scene"] = note
         return out
     finally:
@@ -303,18 +313,71 @@ def video_leg(n_frames, math=None):
     try:
         r, _, _, _ = drivers.make_renderer(1920, 1080, [6, 0, 0.5], 90, n_stars=6000, math=math)
         t0 = time.perf_counter()
+        st = {}
         drivers.render_video(r, 1920, 1080, n_frames=n_frames, fps=30, output_path=os.path.join(tmp, "v.mp4"), fov=90,
-                             static_cam_pos=[6, 0, 0.5], orbit=True, assemble=False, video_stream="off")
+                             static_cam_pos=[6, 0, 0.5], orbit=True, assemble=False, video_stream="off", stats=st)
         dt = time.perf_counter() - t0
         files = [f for f in os.listdir(drivers._frames_dir(os.path.join(tmp, "v.mp4"))) if f.endswith(".png")]
         size = sum(os.path.getsize(os.path.join(drivers._frames_dir(os.path.join(tmp, "v.mp4")), f)) for f in files)
         r.close()
-        return {"fps": n_frames / dt, "frames": n_frames, "png_files": len(files), "mb_per_frame": size / max(len(files), 1) / 1e6,
+        return {"fps": n_frames / st["loop_s"], "fps_incl_setup": n_frames / dt, "setup_s": st["setup_s"], "loop_s": st["loop_s"],
+                "frames": n_frames, "png_files": len(files), "mb_per_frame": size / max(len(files), 1) / 1e6,
                 "png_encoder": "device", "march_math": r.math if hasattr(r, "math") else math,
-                "what": "render_video at 1920x1080: lifecycle init + every frame's populations, "
-                "background / entity / compose passes, march, bloom, PNG file on disk"}
+                "what": "render_video at 1920x1080: every frame's populations, background / entity / compose passes, march, bloom "
+                        "(u8 rows only), PNG file on disk; fps over the frame loop, the one-off resume scan + lifecycle init in setup_s"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def config2_leg(math=None, frames=40):
+    """BASELINE.json configs[2] on this GPU: 3840x2160, disk tilt 25 deg, --anti_alias lod_radius (the march integrates the two
+    variational RK4s and samples the mip stack, render.py:2888-2911, 2961-2990), lens flare applied on the device inside the
+    step (render.py:3925-4028).  fps with two frames in flight; kernel times from isolated launches (one frame slot)."""
+    from bhr_amd import workloads
+    wl = WORKLOADS["4k"]
+    out = {"workload": "4k 3840x2160 default scene, disk_tilt 25, anti_alias lod_radius, lens_flare on (BASELINE.json configs[2])", "march_math": math}
+    for slots in (1, 2):
+        r, _, _, note = workloads.make_scene(wl, math=math, frame_slots=slots)
+        try:
+            t_spin = time.perf_counter()
+            while (time.perf_counter() - t_spin) < 0.3:
+                for _ in range(4):
+                    r.render_async(wl["cam_pos"], wl["fov"], lens_flare=True)
+                r.sync()
+            r.timing_reset()
+            r.sync()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                r.render_async(wl["cam_pos"], wl["fov"], lens_flare=True)
+            r.sync()
+            el = time.perf_counter() - t0
+            c = r.counters()
+            if slots == 1:
+                march_ms = c["march_ms_sum"] / max(c["frames_timed"], 1)
+                steps = c["ray_steps_sum"] / max(c["frames_timed"], 1)
+                out["kernel_ms"] = {"march": march_ms, "bloom_combine_flare": c["bloom_ms_sum"] / max(c["frames_timed"], 1),
+                                    "frames_timed": c["frames_timed"], "how": "HIP events, isolated launches (one frame slot)"}
+                out["fps_one_frame_at_a_time"] = frames / el
+                out["ray_steps_per_frame"] = int(steps)
+                out["scene"] = note
+                # SURVEY 8(d): 625 flop per ray-step with the differentials as the reference writes them (three RK4s), ~330 with the
+                # stage values shared between the main and the variational right-hand sides (what both builds execute)
+                out["roofline_valu"] = {"bound": "valu_fp32", "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "as_the_reference_writes_it": {"flop_per_ray_step": 625.0, "achieved": 625.0 * steps / (march_ms * 1e-3) / 1e12,
+                                                                       "frac": 625.0 * steps / (march_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS},
+                                        "with_stage_reuse": {"flop_per_ray_step": 330.0, "achieved": 330.0 * steps / (march_ms * 1e-3) / 1e12,
+                                                             "frac": 330.0 * steps / (march_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS}}
+                if r.math == "hybrid":
+                    hi = r.hybrid_info()
+                    out["hybrid"] = {"strict_tiles": hi["strict_tiles"], "tiles": hi["tiles"], "repaired_pixels": hi["repaired_pixels"]}
+            else:
+                out["fps"] = frames / el
+                out["ms_per_frame"] = el / frames * 1e3
+                out["value"] = c["ray_steps_sum"] / max(c["frames_timed"], 1) * frames / el / 1e6
+                out["unit"] = "Mray-steps/s"
+        finally:
+            r.close()
+    return out
 
 
 def main():
@@ -588,22 +651,28 @@ def main():
                     nt = args.tile_tail_tiles
                     tt = tile_tail_leg(WORKLOADS[args.tile_workload], nt, math=args.math, reps=6)
                     per = {sch: [round(r[f"e2e_ms_{sch}_peer_u8"], 3) for r in tt["per_tile"]] for sch in ("serial", "pipelined")}
-                    copies = tt["xgmi_copy_ms"]["halo_pull"] + tt["xgmi_copy_ms"]["u8_rows"]
                     tile["one_tile_alone"] = {"workload": tt["workload"], "row_blocks": tt["row_blocks"], "per_tile_ms": per,
                                               "per_tile_march_alone_ms": [round(r["march_alone_ms"], 3) for r in tt["per_tile"]],
                                               "slowest_tile": tt["slowest_tile"], "tile_ms": tt["tile_ms"], "tile_march_alone_ms": tt["tile_march_alone_ms"],
                                               "tile_tail_ms": tt["tile_tail_ms"], "tile_tail_frac": tt["tile_tail_frac"], "schedule": tt["schedule"],
-                                              "xgmi_copy_ms": tt["xgmi_copy_ms"]}
+                                              "peer_store_mb": tt["peer_store_mb"]}
                     tile["tile_tail_ms"] = tt["tile_tail_ms"]
-                    # serial schedule: the copies follow the V pass, add their xGMI time; pipelined: they hide under the V pass
+                    # no copy stages any more: the H pass stores its halo rows into the neighbours' planes, the V pass its u8 rows into
+                    # the frame buffer on tile 0's device -- on N devices those stores cross xGMI inside the kernels (14 + 12 MB per
+                    # 8k tile), which one device cannot show
                     tile[f"predicted_efficiency_at_{nt}_gpus"] = {
-                        "serial_schedule_plus_xgmi_copies": tile["ms_per_frame"] / (nt * (max(per["serial"]) + copies)),
+                        "serial_schedule": tile["ms_per_frame"] / (nt * max(per["serial"])),
                         "pipelined_schedule": tile["ms_per_frame"] / (nt * max(per["pipelined"])),
-                        "note": "one-GPU frame time / (tiles x slowest tile alone, first march launch .. rows landed in the frame buffer); measured on ONE "
-                                "device, where a tile's copies are HBM to HBM: the serial figure adds what the halo pull and the u8 rows would take on a "
-                                "153 GB/s link, the pipelined schedule overlaps them with the V pass"}
+                        "note": "PREDICTED, unmeasured on more than one device: one-GPU frame time / (tiles x slowest tile alone, first march launch "
+                                ".. its V pass done, halo rows and frame rows stored by the kernels themselves); on this one device the "
+                                "neighbours' planes and the frame buffer are local HBM, on N they are peer memory over xGMI"}
                 except Exception as e:
                     tile["one_tile_alone"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_other_math and not args.no_config2:
+            try:
+                out["config2_4k"] = config2_leg(math=args.math)
+            except Exception as e:      # the headline stands on its own
+                out["config2_4k"] = {"error": f"{type(e).__name__}: {e}"}
         if args.video_frames > 0 and world == 1 and not args.no_other_math:
             try:
                 out["video_loop"] = video_leg(args.video_frames, math=args.math)

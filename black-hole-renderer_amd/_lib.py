@@ -14,7 +14,7 @@ BHR_OK = 0
 BHR_ERR_INVALID, BHR_ERR_NO_DEVICE, BHR_ERR_HIP, BHR_ERR_STATE, BHR_ERR_NOMEM = -1, -2, -3, -4, -5
 
 SKIP_DIFFERENTIALS, SKIP_BLOOM, PERSISTENT, FORCE_FAST, FORCE_STRICT, LENS_FLARE, ROW_COSTS, GATHER_PEER = 1, 2, 4, 8, 16, 32, 64, 128
-FORCE_HYBRID, GATHER_U8, GROUP_SERIAL, GROUP_PIPELINED = 256, 512, 1024, 2048
+FORCE_HYBRID, GATHER_U8, GROUP_SERIAL, GROUP_PIPELINED, GROUP_TIME_MARCH = 256, 512, 1024, 2048, 4096
 MATH_FAST, MATH_STRICT, MATH_HYBRID = 0, 1, 2
 LAYER_FINAL, LAYER_BG, LAYER_DISK, LAYER_BLUR = 0, 1, 2, 3
 OUTPUT_F32, OUTPUT_BLUR, OUTPUT_U8 = 1, 2, 4

@@ -38,6 +38,7 @@ void activate_slot(bhr_ctx *ctx, int k) {
     ctx->d_hblur = f.d_hblur;
     ctx->d_pa = f.d_pa;
     ctx->d_pb = f.d_pb;
+    ctx->d_sum = f.d_sum;
     ctx->d_blur = f.d_blur;
     ctx->d_final = f.d_final;
     ctx->d_final_u8 = f.d_final_u8;
@@ -76,6 +77,8 @@ static void read_options(bhr_options *o) {
         if (sscanf(e, "%lf,%lf", &lo, &hi) == 2 && lo >= 0 && hi >= 0) { o->hybrid_band[0] = lo; o->hybrid_band[1] = hi; o->hybrid_band_set = 1; }
     }
     o->hybrid_streams = num("BHR_HYBRID_STREAMS", 2) == 1 ? 1 : 2;
+    o->hybrid_classify = num("BHR_HYBRID_CLASSIFY", 1) != 0;
+    o->hybrid_swap = num("BHR_HYBRID_SWAP", 1) != 0;
     o->mip_lds = num("BHR_MIP_LDS", 0) != 0;
     { const char *e = getenv("BHR_TILE_ORDER"); o->tile_order_rows = e && e[0] == 'r'; }
     o->tile_block = num("BHR_TILE_BLOCK", 256);
@@ -97,7 +100,6 @@ int32_t alloc_slot(bhr_ctx *ctx, int k) {
         else { pad_streams(ctx, k == 0 ? 0 : 1); BHR_HIP(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking)); }
     }
     if (!f.done) BHR_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
-    if (!f.march_done) BHR_HIP(hipEventCreateWithFlags(&f.march_done, hipEventDisableTiming));
     int32_t rc = BHR_OK;
     (void)R;
     if ((rc = dev_alloc(&f.d_bg, px3)) || (rc = dev_alloc(&f.d_disk, px3)) || (rc = dev_alloc(&f.d_blur, px3)) ||
@@ -126,6 +128,7 @@ int32_t ensure_bloom_buffers(bhr_ctx *ctx, int k, bool split) {
         bhr_split_geometry(ctx, &g);
         BHR_HIP(hipMalloc(&f.d_pa, g.pa_halfs * 2));
         BHR_HIP(hipMalloc(&f.d_pb, g.pb_halfs * 2));
+        BHR_TRY(dev_alloc(&f.d_sum, rows * W * 3));
         BHR_HIP(hipMemsetAsync(f.d_pa, 0, g.pa_halfs * 2, ctx->scene_stream));
         BHR_HIP(hipMemsetAsync(f.d_pb, 0, g.pb_halfs * 2, ctx->scene_stream));
     } else {
@@ -141,12 +144,11 @@ int32_t ensure_bloom_buffers(bhr_ctx *ctx, int k, bool split) {
 
 void free_slot(bhr_ctx *ctx, int k) {
     bhr_frame_slot &f = ctx->slots[k];
-    void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur_base, f.d_pa, f.d_pb, f.d_queue,
+    void *bufs[] = {f.d_bg, f.d_disk, f.d_blur, f.d_final, f.d_final_u8, f.d_hblur_base, f.d_pa, f.d_pb, f.d_sum, f.d_queue,
                     f.d_glow_hw, f.d_glow_wh, f.d_flare_c0, f.d_flare_c12, f.d_flare_sums};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (f.done) (void)hipEventDestroy(f.done);
-    if (f.march_done) (void)hipEventDestroy(f.march_done);
     if (f.stream && f.stream != ctx->scene_stream) (void)hipStreamDestroy(f.stream);
     memset(&f, 0, sizeof(f));
 }
@@ -261,9 +263,11 @@ int32_t bhr_frame_begin(bhr_ctx *ctx, uint32_t flags) {
         ctx->d_hblur = f.d_hblur;
         ctx->d_pa = f.d_pa;
         ctx->d_pb = f.d_pb;
+        ctx->d_sum = f.d_sum;
     }
     bhr_frame_slot &f = ctx->slots[ctx->active_slot];
     f.have = 0;
+    f.sum_valid = 0;
     f.frame_split = split;
     f.frame_with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     return BHR_OK;
@@ -379,7 +383,7 @@ int32_t bhr_enter_scene_write(bhr_ctx *ctx) {
     BHR_HIP(hipSetDevice(ctx->cfg.device));
     for (int k = 0; k < BHR_MAX_FRAME_SLOTS; ++k) {
         bhr_frame_slot &f = ctx->slots[k];
-        if (f.in_flight && f.stream != ctx->scene_stream) BHR_HIP(hipStreamWaitEvent(ctx->scene_stream, f.march_done, 0));
+        if (f.in_flight && f.stream != ctx->scene_stream && f.march_done) BHR_HIP(hipStreamWaitEvent(ctx->scene_stream, f.march_done, 0));
     }
     ctx->stream = ctx->scene_stream;
     return BHR_OK;
@@ -703,7 +707,9 @@ int32_t render_on_slot(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags, int 
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     BHR_TRY(bhr_frame_begin(ctx, flags));
     BHR_TRY(bhr_launch_march(ctx, cam, flags));  // records the ring slot's march events
-    BHR_HIP(hipEventRecord(f.march_done, f.stream));
+    // the march's end is the timing ring's event (recorded by the launcher): an event of its own between the march and the
+    // H pass is another ~5 us barrier packet in the frame's stream (kernel-trace gaps: 10 us with two records, 0 with none)
+    f.march_done = ctx->ring_ev[ring * 3 + 1];
     if (with_bloom) BHR_TRY(bhr_launch_bloom_h(ctx));
     // the V kernel clears the counter cell BHR_MAX_FRAME_SLOTS frames ahead: no frame that may be in flight on another
     // slot's stream is counting into it (the next frames' marches may already be running)
@@ -782,8 +788,8 @@ int32_t bhr_write_layer(bhr_ctx *ctx, int32_t layer, const float *in) {
     bhr_frame_slot &f = ctx->slots[ctx->active_slot];
     switch (layer) {
         case BHR_LAYER_FINAL: dst = ctx->d_final; f.have = (f.have | BHR_OUT_F32) & ~BHR_OUT_U8; break;   // the u8 rows follow the written frame
-        case BHR_LAYER_BG: dst = ctx->d_bg; break;
-        case BHR_LAYER_DISK: dst = ctx->d_disk; break;
+        case BHR_LAYER_BG: dst = ctx->d_bg; f.sum_valid = 0; break;      // a later V pass adds the two layers itself
+        case BHR_LAYER_DISK: dst = ctx->d_disk; f.sum_valid = 0; break;
         case BHR_LAYER_BLUR: dst = ctx->d_blur; f.have |= BHR_OUT_BLUR; break;
         default: return bhr_fail(BHR_ERR_INVALID, "bhr_write_layer: unknown layer %d", layer);
     }
@@ -807,6 +813,15 @@ int32_t bhr_debug_read(bhr_ctx *ctx, int32_t which, void *out, int64_t bytes, in
     bhr_split_geom g;
     bhr_split_geometry(ctx, &g);
     if (geom) { geom[0] = g.NT; geom[1] = g.n_tx; geom[2] = g.WP; geom[3] = g.YB; geom[4] = g.GP; geom[5] = g.g0; geom[6] = g.t_first; geom[7] = g.n_ty; geom[8] = g.pbr; geom[9] = g.GR; }
+    if (which == 2) {                                   // the partitioned launch order of the last hybrid march (int32 tile indices)
+        const int32_t *list = nullptr;
+        int32_t n = 0;
+        BHR_TRY(bhr_hybrid_active_list(ctx, &list, &n));
+        if (geom) geom[0] = n;
+        if (!out || bytes == 0) return BHR_OK;
+        if (bytes > (int64_t)n * 4) return bhr_fail(BHR_ERR_INVALID, "bhr_debug_read: %lld bytes asked, the list holds %d tiles", (long long)bytes, n);
+        return download(ctx, out, list, (size_t)bytes);
+    }
     const void *src = which == 0 ? ctx->d_pa : which == 1 ? ctx->d_pb : nullptr;
     const size_t have = which == 0 ? g.pa_halfs * 2 : g.pb_halfs * 2;
     if (!out || bytes == 0) return BHR_OK;
@@ -828,6 +843,8 @@ int32_t bhr_set_option(bhr_ctx *ctx, const char *name, double value) {
     else if (n == "hybrid_band_hi") { if (!o.hybrid_band_set) o.hybrid_band[0] = 0.085; o.hybrid_band[1] = value; o.hybrid_band_set = 1; }
     else if (n == "hybrid_band_default") o.hybrid_band_set = 0;
     else if (n == "hybrid_streams") o.hybrid_streams = v == 1 ? 1 : 2;
+    else if (n == "hybrid_classify") o.hybrid_classify = v != 0;
+    else if (n == "hybrid_swap") o.hybrid_swap = v != 0;
     else if (n == "mip_lds") o.mip_lds = v != 0;
     else if (n == "tile_order_rows") o.tile_order_rows = v != 0;
     else if (n == "group_threads") o.group_threads = v < 0 ? -1 : (v ? 1 : 0);
@@ -889,8 +906,8 @@ int32_t bhr_get_counters(bhr_ctx *ctx, bhr_counters *out) {
         ctx->counters.ray_steps = steps;
         // the last launch's three events: its ring slot's (bhr_render) or the context's scalar ones (group render)
         const hipEvent_t *e = ctx->last_slot >= 0 ? ctx->ring_ev + ctx->last_slot * 3 : ctx->ev;
-        ctx->counters.march_ms = ev_ms(e[0], e[1]);
-        ctx->counters.bloom_ms = ev_ms(e[1], e[2]);
+        ctx->counters.march_ms = ctx->march_end_recorded ? ev_ms(e[0], e[1]) : -1.0f;      // a group render without BHR_GROUP_TIME_MARCH: not timed
+        ctx->counters.bloom_ms = ctx->march_end_recorded ? ev_ms(e[1], e[2]) : -1.0f;
         ctx->counters.frame_ms = ev_ms(e[0], e[2]);
     }
     {

@@ -81,6 +81,7 @@ struct BhrMarchArgs {
     float *disk;             // (rows, width, 3)
     _Float16 *diskp;         // non-null: the disk layer once more, cut into f16 halves in the bloom H pass's operand order (bloom.hip: pa)
     int32_t dp_yb, dp_gp, dp_g0;
+    float *sum;              // with diskp: bg + disk per value (the V pass's combine reads one plane instead of two)
     unsigned long long *ray_steps;
     unsigned int *queue;     // persistent-wave work counter (zeroed before launch)
     const bhr_disk_v2_params *dv2;   // non-null: analytic Disk V2 source instead of the texture
@@ -127,6 +128,8 @@ struct bhr_options {
     double hybrid_band[2];      // BHR_HYBRID_BAND="lo,hi": strict band around b_c in r_s (default 0.085, 0.36)
     int32_t hybrid_band_set;
     int32_t hybrid_streams;     // BHR_HYBRID_STREAMS: 1 both lists of a hybrid march on one stream, 2 (default) on two
+    int32_t hybrid_swap;        // BHR_HYBRID_SWAP: 1 (default) the fast list on the frame's stream and the strict one on the second, 0 the other way round
+    int32_t hybrid_classify;    // BHR_HYBRID_CLASSIFY: 1 (default) the tiles are classified and the launch order partitioned on the device, 0 on the host
     int32_t mip_lds;            // BHR_MIP_LDS=1: anti-aliased fast frames stage the coarse mip levels in LDS
     int32_t tile_order_rows;    // BHR_TILE_ORDER=row: row-major march launch order (A/B runs)
     int32_t tile_block;         // BHR_TILE_BLOCK: threads per march workgroup (64 / 128 / 256)
@@ -159,6 +162,8 @@ struct bhr_frame_slot {
     float *d_bg, *d_disk, *d_hblur, *d_blur, *d_final;
     float *d_hblur_base;       // the allocation d_hblur points BHR_HBLUR_PAD_ROWS rows into (zero rows in front of plane 0 and behind plane 2); exact-f32 bloom, on first use
     void *d_pa, *d_pb;         // split-f16 bloom (bloom.hip): the march's packed copy of the disk layer, the packed H-blur planes; on first use
+    float *d_sum;              // ... and bg + disk of the frame (rows, W, 3); sum_valid: written by this frame's march / pack kernel
+    int32_t sum_valid;
     uint8_t *d_final_u8;
     uint32_t have;             // BHR_OUT_* layers of the slot's last frame that are in memory (the V pass stores what was asked for; the rest on demand)
     int32_t frame_split, frame_with_bloom;   // how that frame's post-pass ran (bhr_ensure_outputs re-runs its V pass)
@@ -168,7 +173,7 @@ struct bhr_frame_slot {
     double *d_flare_c12, *d_flare_sums;
     int64_t flare_glow_rows;
     hipEvent_t done;        // end of the slot's last bhr_render (and of frame work queued behind it: bhr_leave_frame)
-    hipEvent_t march_done;  // end of its march: the last reader of the scene (bhr_enter_scene_write)
+    hipEvent_t march_done;  // end of its last march: the last reader of the scene (bhr_enter_scene_write); borrowed from the timing ring
     int32_t allocated;
     int32_t in_flight;      // rendered since the last join
 };
@@ -233,6 +238,7 @@ struct bhr_ctx {
     float *d_wext;             // unfolded weights (3, 2 R4 + 8)
     unsigned short *d_w16;     // split-f16 weight table: 3 channels x 2 halves x 8 shifted copies (bloom.hip: bloom_tables_kernel)
     void *d_pa, *d_pb;         // the active slot's packed bloom operands (null until a split frame needs them)
+    float *d_sum;
     int32_t mip_lds_from;      // first mip level the last anti-aliased fast march staged in LDS (BHR_MIP_LDS), -1: none
     int32_t bloom_split;       // post-pass of the current frame: 0 exact f32 kernels (strict), 1 split-f16 matrix-core kernels (fast / hybrid)
     int32_t split_ok;          // the context's radius fits the split kernels' table (R <= 176)
@@ -281,6 +287,8 @@ struct bhr_ctx {
     bhr_counters counters;
     int32_t last_flags;
     int32_t timing_valid;
+    int32_t group_time_march;  // group / tile renders: also record the march-end event (BHR_GROUP_TIME_MARCH); off, the tile's stream carries no event between march and H pass
+    int32_t march_end_recorded;
 };
 
 // error plumbing (api.hip)
@@ -325,6 +333,7 @@ int32_t bhr_selftest_strict(bhr_ctx *ctx, unsigned long long *d_out4);
 int32_t bhr_ensure_tile_order(bhr_ctx *ctx);                                               // march.o: builds d_/h_tile_order
 int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags);     // hybrid.hip
 void bhr_hybrid_free(bhr_ctx *ctx);
+int32_t bhr_hybrid_active_list(bhr_ctx *ctx, const int32_t **list, int32_t *n);   // hybrid.o: the active slot's partitioned launch order (tests)
 int32_t bhr_bloom_prepare(bhr_ctx *ctx);
 int32_t bhr_split_nt(int32_t R);
 void bhr_split_geometry(const bhr_ctx *ctx, bhr_split_geom *g);

@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 //   pa  H-pass input, written by the march kernel (or bloom_pack_kernel)
 //       [c][p][yb = y / 32][g = x / 8 + g0][y % 32][x % 8],  g0 = 2 NT - 2 zero groups in front, GP groups per row block
 //   pb  H-pass output = V-pass input, rows in PLANE coordinates pr = global row - pbr, pbr = 32 floor(row0 / 32) - 16 (NT - 1)
-//       [c][p][gr = pr / 8][x < WP][pr % 8],  WP = W rounded up to 32, GR groups; rows outside the image stay zero
+//       [c][p][strip = x / 32][gr = pr / 8][x % 32][pr % 8],  n_tx strips (WP = 32 n_tx >= W), GR groups per strip; rows outside the
+//       image stay zero.  A V-pass wave (one strip) streams contiguous memory, 1 KB per chunk; an H-pass tile (one strip, four
+//       groups) stores 2 KB contiguous per half.
 // In both, chunk' k (16 taps) is the pair of groups 2 k, 2 k + 1 and tile' t (32 outputs) lives on chunks [2 t, 2 t + 2 NT - 1]
 // with Toeplitz offset delta = 16 (chunk' - 2 t - NT + 1).  (H: tile' = x / 32, chunk' = (x + 16 (NT - 1)) / 16.)
 struct Mirror {                // a neighbouring row block's pb planes, written by this block's H pass where they hold its rows
@@ -349,7 +351,7 @@ struct HSplitArgs {
     int32_t W, WP, rows, row0;
     int32_t YB, GP, GR, pbr;
     int32_t NT, table_bytes, n_tx;
-    int32_t seg;               // output tiles per wave (<= T)
+    int32_t seg, n_seg;        // output tiles per wave (<= T), segments per row of tiles
     int32_t dbg;
     int32_t n_mirror;
     Mirror mirror[MAX_MIRRORS];
@@ -358,14 +360,14 @@ struct VSplitArgs {
     const _Float16 *pb;
     const unsigned short *w16;
     const float *wsum_v;       // (3, H)
-    const float *bg, *disk;
+    const float *sum;          // bg + disk of the frame: written by its march beside the packed disk layer, else by bloom_sum_kernel
     VOut out;
     unsigned long long *zero_cell;
     int32_t W, WP, H, row0;
     int32_t GR, t_first;       // t_first = floor(row0 / 32): global tile of tile' 0
-    int32_t NT, table_bytes;
+    int32_t NT, table_bytes, R;
     int32_t seg_t0, seg_t1;    // tiles' of this launch
-    int32_t seg;               // output tiles per wave (<= T)
+    int32_t seg, n_seg;        // output tiles per wave (<= T), segments per strip
     int32_t dbg;
     int32_t r_begin, r_end;    // local rows it stores
 };
@@ -414,9 +416,15 @@ __device__ __forceinline__ const unsigned char *weight_base(const unsigned char 
         ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(BHR_F16X8(WH), BHR_F16X8(DH), ACC, 0, 0, 0);       \
     } while (0)
 
+__global__ void bloom_sum_kernel(const float *__restrict__ bg, const float *__restrict__ disk, float *__restrict__ sum, long long n) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) sum[k] = __fadd_rn(bg[k], disk[k]);
+}
+
 // (rows, W, 3) f32 disk layer -> pa, for frames whose disk layer did not come from this library's march (bhr_bloom on
 // written layers).  One thread per (row, 8-pixel group).
-__global__ void bloom_pack_kernel(const float *__restrict__ disk, _Float16 *__restrict__ pa, int W, int rows, int YB, int GP, int g0) {
+__global__ void bloom_pack_kernel(const float *__restrict__ disk, const float *__restrict__ bg, float *__restrict__ sum, _Float16 *__restrict__ pa, int W, int rows,
+                                  int YB, int GP, int g0) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (g * 8 >= W) return;
     const size_t part = (size_t)YB * GP * 256;
@@ -436,20 +444,26 @@ __global__ void bloom_pack_kernel(const float *__restrict__ disk, _Float16 *__re
         *reinterpret_cast<f16x8 *>(pa + at) = hi;
         *reinterpret_cast<f16x8 *>(pa + at + part) = lo;
     }
+    for (int k = 0; k < 24 && (g * 8) * 3 + k < W * 3; ++k) {          // bg + disk: what the march writes beside its packed copy
+        const size_t at = ((size_t)y * W + g * 8) * 3 + k;
+        sum[at] = __fadd_rn(bg[at], disk[at]);
+    }
 }
 
-// H pass.  Block = 6 waves = the three channels of two 32-row blocks (yb), T output tiles along x each, sharing one copy of
-// the weight table; grid (ceil(n_tx / T), ceil(YB / 2)).
+// H pass.  Work unit = (32-row block yb, segment of `seg` <= T output tiles along x); a workgroup = 6 waves = the three
+// channels of two consecutive units, sharing one copy of the weight table; grid ceil(units / 2).
 template <int T>
 __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T == 8 ? 2 : 3, T == 8 ? 2 : 3))) void bloom_h_split_kernel(HSplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
-    stage_table(lds_b, a.w16, a.table_bytes, (a.dbg & 8) != 0);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ch = wave % 3, yb = blockIdx.y * SPLIT_SUBS + wave / 3;
-    if (yb >= a.YB) return;
-    const int n = lane & 31, h = lane >> 5, NT = a.NT;
-    const int tb = blockIdx.x * a.seg, te = min(tb + a.seg, a.n_tx);
+    const int ch = wave % 3, unit = blockIdx.x * SPLIT_SUBS + wave / 3;
+    if (unit >= a.n_seg * a.YB) {                    // no work: only the workgroup's table staging
+        stage_table(lds_b, a.w16, a.table_bytes, (a.dbg & 8) != 0);
+        __syncthreads();
+        return;
+    }
+    const int yb = unit / a.n_seg, n = lane & 31, h = lane >> 5, NT = a.NT;
+    const int tb = (unit - yb * a.n_seg) * a.seg, te = min(tb + a.seg, a.n_tx);
     const int part_w = 8 * split_csb(NT);
     // tile i of the wave at chunk' cp reads the window k = cp - 2 (tb + i): one address per chunk, immediate offsets per tile
     const unsigned char *wl = weight_base(lds_b, ch, NT, n, h) - 64 * (T - 1);
@@ -481,10 +495,13 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
             }
         }
     };
-    // SPLIT_DEPTH chunks in flight per wave: a chunk's MFMAs (<= 3 T x 32 cycles) are far shorter than a trip to memory
+    // SPLIT_DEPTH chunks in flight per wave: a chunk's MFMAs (<= 3 T x 32 cycles) are far shorter than a trip to memory.  The
+    // first ones are on their way before the workgroup stages its weight table (neither waits for the other)
     u32x4 d[SPLIT_DEPTH][2];
 #pragma unroll
     for (int j = 0; j < SPLIT_DEPTH; ++j) load(c0 + j, d[j]);
+    stage_table(lds_b, a.w16, a.table_bytes, (a.dbg & 8) != 0);
+    __syncthreads();
     for (int cp = c0; cp <= ((a.dbg & 1) ? c0 : c1); cp += SPLIT_DEPTH) {
 #pragma unroll
         for (int j = 0; j < SPLIT_DEPTH; ++j) {
@@ -500,75 +517,104 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
         return;
     }
 
-    // D: column = lane & 31 -> output pixel, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> row of the block.  A lane's four
-    // registers of a quad are four consecutive rows: 8 bytes of one pb group, next to the 8 bytes of lane + 32.
-    const size_t part_b = (size_t)a.GR * a.WP * 8;
-    const bool quads_aligned = ((a.row0 - a.pbr) & 3) == 0;
+    // D: column = lane & 31 -> output pixel, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> row of the block: a lane's four
+    // registers of quad q are rows 8 q + 4 h .. + 3 of its column -- half a pb group (8 rows = 16 bytes per half).  Lanes l and
+    // l + 32 hold the two halves of the same groups: one v_permlane32_swap per register pair hands the lower lanes all of
+    // group q and the upper lanes all of group q + 1, so every lane stores 16 bytes (1 KB contiguous per instruction; 8-byte
+    // stores were store-issue bound: 31 of the 130 us of an 8k row block's post-pass).
+    const bool aligned8 = ((a.row0 - a.pbr) & 7) == 0;
+    // 2^-10 / (in-bounds weight sum) of every tile's column, all T loads in one batch: loaded tile by tile, each was a trip to
+    // L2 behind an s_waitcnt vmcnt(0) that also waited for the previous tile's stores to land (stores count in vmcnt on gfx9)
+    float wsv[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const int x = 32 * (tb + i) + n;
+        wsv[i] = (tb + i < te && x < a.W) ? a.wsum_h[(3 + ch) * a.W + x] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i) asm volatile("" : "+v"(wsv[i]));          // all of them HERE: no load is left to wait for between the tiles' stores
 #pragma unroll
     for (int i = 0; i < T; ++i) {
         if (tb + i >= te) continue;
         const int x = 32 * (tb + i) + n;
-        if (x >= a.W) continue;
-        float ws = a.wsum_h[(3 + ch) * a.W + x];             // 2^-10 / (in-bounds weight sum): a sum back to a scaled pixel
-        if (a.dbg & 4) ws = HB_RESCALE / a.wsum_h[ch * a.W + x];
+        const float ws = wsv[i];                                           // a sum back to a scaled pixel
+        unsigned int ph[4][2], pl[4][2];                                   // [quad][dword]: 4 rows x f16, hi and lo halves
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int yq = 32 * yb + 8 * q + 4 * h;                   // local row of the quad
-            if (yq >= a.rows) continue;
             _Float16 hi[4], lo[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) cut2(acc[i][4 * q + j] * ws, hi[j], lo[j]);
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                ph[q][d] = __builtin_bit_cast(unsigned int, (f16x2){hi[2 * d], hi[2 * d + 1]});
+                pl[q][d] = __builtin_bit_cast(unsigned int, (f16x2){lo[2 * d], lo[2 * d + 1]});
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q += 2)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                auto r = __builtin_amdgcn_permlane32_swap(ph[q][d], ph[q + 1][d], false, false);
+                ph[q][d] = r[0]; ph[q + 1][d] = r[1];
+                r = __builtin_amdgcn_permlane32_swap(pl[q][d], pl[q + 1][d], false, false);
+                pl[q][d] = r[0]; pl[q + 1][d] = r[1];
+            }
+        if (x >= a.W) continue;
+#pragma unroll
+        for (int q = 0; q < 4; q += 2) {
+            // this lane's group: rows 8 (q + h) .. + 7 of the block, halves {ph[q], ph[q + 1]} (rows 0-3 from the lower lane, 4-7 from the upper)
+            const int yq = 32 * yb + 8 * (q + h);                      // local row of the group's first row
+            if (yq >= a.rows) continue;
+            const u32x4 vh = {ph[q][0], ph[q][1], ph[q + 1][0], ph[q + 1][1]}, vl = {pl[q][0], pl[q][1], pl[q + 1][0], pl[q + 1][1]};
             const int gq = a.row0 + yq;                                // global row
-            const bool whole = quads_aligned && yq + 3 < a.rows;
-            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-            const f16x4 vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
+            const bool whole = aligned8 && yq + 7 < a.rows;
             auto put = [&](_Float16 *pb, int pbr, int pend, int gr) {
-                const size_t part = (size_t)gr * a.WP * 8;
+                const size_t part = (size_t)a.n_tx * gr * 256;
+                _Float16 *base = pb + ((((size_t)(ch * 2) * a.n_tx + (tb + i)) * gr) * 32 + n) * 8;      // + 256 halfs per group
                 if (whole) {
-                    if (gq < pbr || gq + 3 >= pend) return;
-                    const int pr = gq - pbr;
-                    _Float16 *dst = pb + (((size_t)(ch * 2) * gr + (pr >> 3)) * a.WP + x) * 8 + (pr & 7);
-                    *reinterpret_cast<f16x4 *>(dst) = vh;
-                    *reinterpret_cast<f16x4 *>(dst + part) = vl;
+                    if (gq < pbr || gq + 7 >= pend) return;
+                    _Float16 *dst = base + (size_t)((gq - pbr) >> 3) * 256;
+                    *reinterpret_cast<u32x4 *>(dst) = vh;
+                    *reinterpret_cast<u32x4 *>(dst + part) = vl;
                 } else {
-                    for (int j = 0; j < 4; ++j) {
+                    const f16x8 eh = BHR_F16X8(vh), el = BHR_F16X8(vl);
+                    for (int j = 0; j < 8; ++j) {
                         const int g = gq + j;
                         if (yq + j >= a.rows || g < pbr || g >= pend) continue;
                         const int pr = g - pbr;
-                        _Float16 *dst = pb + (((size_t)(ch * 2) * gr + (pr >> 3)) * a.WP + x) * 8 + (pr & 7);
-                        dst[0] = hi[j];
-                        dst[part] = lo[j];
+                        _Float16 *dst = base + (size_t)(pr >> 3) * 256 + (pr & 7);
+                        dst[0] = eh[j];
+                        dst[part] = el[j];
                     }
                 }
             };
-            (void)part_b;
             put(a.pb, a.pbr, a.pbr + 8 * a.GR, a.GR);
             for (int m = 0; m < a.n_mirror; ++m) put(a.mirror[m].pb, a.mirror[m].pbr, a.mirror[m].pend, a.mirror[m].gr);
         }
     }
 }
 
-// V pass + combine.  Block = 6 waves = the three channels of two adjacent 32-column strips, T stacked output tiles each;
-// grid (ceil(WP / 64), ceil((seg_t1 - seg_t0) / T)).
+// V pass + combine.  Work unit = (segment of `seg` <= T stacked output tiles, 32-column strip), strips fastest; a workgroup
+// = 6 waves = the three channels of two consecutive units; grid ceil(units / 2).
 template <int T>
 __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T == 8 ? 2 : 3, T == 8 ? 2 : 3))) void bloom_v_split_kernel(VSplitArgs a) {
-    if (a.zero_cell && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < BHR_STEP_LANES)
+    if (a.zero_cell && blockIdx.x == 0 && threadIdx.x < BHR_STEP_LANES)
         a.zero_cell[(size_t)threadIdx.x * BHR_STEP_STRIDE] = 0ull;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
-    stage_table(lds_b, a.w16, a.table_bytes, (a.dbg & 8) != 0);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ch = wave % 3, sub = wave / 3;
-    int strip = blockIdx.x * SPLIT_SUBS + sub;
-    const bool live = strip * 32 < a.WP;             // a strip past the image walks strip 0's rows and stores nothing: every wave reaches the barriers below
-    if (!live) strip = 0;
+    const int ch = wave % 3, sub = wave / 3, n_strips = a.WP / 32;
+    int unit = blockIdx.x * SPLIT_SUBS + sub;
+    const bool live = unit < a.n_seg * n_strips;     // a unit past the end walks unit 0 and stores nothing: every wave reaches the barriers below
+    if (!live) unit = 0;
+    const int yseg = unit / n_strips, strip = unit - yseg * n_strips;
     const int n = lane & 31, h = lane >> 5, NT = a.NT;
     const int x = strip * 32 + n;
-    const int tb = a.seg_t0 + blockIdx.y * a.seg, te = min(tb + a.seg, a.seg_t1);
+    const int tb = a.seg_t0 + yseg * a.seg, te = min(tb + a.seg, a.seg_t1);
     const int part_w = 8 * split_csb(NT);
     const unsigned char *wl = weight_base(lds_b, ch, NT, n, h) - 64 * (T - 1);
-    const size_t part_b = (size_t)a.GR * a.WP * 8, chunk_b = (size_t)a.WP * 16;
-    const _Float16 *src = a.pb + (((size_t)(ch * 2) * a.GR + h) * a.WP + x) * 8;
+    const size_t part_b = (size_t)(a.WP / 32) * a.GR * 256, chunk_b = 512;                  // halfs: the strip's groups are contiguous
+    const _Float16 *src = a.pb + ((((size_t)(ch * 2) * (a.WP / 32) + strip) * a.GR + h) * 32 + n) * 8;
 
     f32x16 acc[T];
 #pragma unroll
@@ -598,6 +644,8 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     u32x4 d[SPLIT_DEPTH][2];
 #pragma unroll
     for (int j = 0; j < SPLIT_DEPTH; ++j) load(c0 + j, d[j]);
+    stage_table(lds_b, a.w16, a.table_bytes, (a.dbg & 8) != 0);
+    __syncthreads();
     for (int cp = c0; cp <= ((a.dbg & 1) ? c0 : c1); cp += SPLIT_DEPTH) {
 #pragma unroll
         for (int j = 0; j < SPLIT_DEPTH; ++j) {
@@ -614,6 +662,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     }
 
     const float *__restrict__ winv = a.wsum_v + (size_t)(3 + ch) * a.H;    // 2^-24 / (in-bounds weight sum) of every image row
+    const float winv_mid = winv[a.H >> 1];
     // Epilogue.  The accumulators hold one channel of a tile with the column on the lane: stored from here, a wave would touch
     // 4 bytes of every 12 of the interleaved (rows, W, 3) layers, three waves one after the other, and single bytes of the u8
     // rows (measured: 80 of the 110 us of an 8k row block's V pass, 50 of fhd's 57).  Instead the three channel waves of a
@@ -621,11 +670,13 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     // 768 float4s: 16-byte loads of bg and disk, 16-byte stores of the f32 frame and the blur, 4-byte stores of the u8
     // rows, every instruction on whole 384-byte row segments.  (Widths that are not multiples of 4 and the partial strip at the
     // right edge keep the per-channel path.)
-    const bool coop = (a.W & 3) == 0 && (blockIdx.x + 1) * SPLIT_SUBS * 32 <= a.W && !(a.dbg & 4);      // uniform over the workgroup
+    // uniform over the workgroup: both of its units are whole strips of the SAME segment (the tile loop below is shared)
+    const int u0 = blockIdx.x * SPLIT_SUBS, u1 = u0 + SPLIT_SUBS - 1;
+    const bool coop = (a.W & 3) == 0 && u1 < a.n_seg * n_strips && u0 / n_strips == u1 / n_strips && (u1 % n_strips + 1) * 32 <= a.W && !(a.dbg & 4);
     float *tile = reinterpret_cast<float *>(lds_b + a.table_bytes) + sub * (32 * 96);
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-        if (tb + i >= te) continue;                                     // uniform over the workgroup
+        if (tb + i >= te) continue;                                     // coop: uniform over the workgroup (one segment)
         const int yg0 = 32 * (a.t_first + tb + i);
         if (!coop) {
             if (!live || x >= a.W) continue;
@@ -633,32 +684,61 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
             for (int r = 0; r < 16; ++r) {
                 const int yg = yg0 + (r & 3) + 8 * (r >> 2) + 4 * h, yl = yg - a.row0;
                 if (yl < a.r_begin || yl >= a.r_end) continue;
-                combine_store(a.out, a.bg, a.disk, ((size_t)yl * a.W + x) * 3 + ch, acc[i][r] * winv[yg]);
+                const size_t at = ((size_t)yl * a.W + x) * 3 + ch;
+                const float b = acc[i][r] * winv[yg];
+                if (a.out.blur) a.out.blur[at] = b;
+                if (a.out.final_f32 || a.out.u8) {
+                    const float f = fminf(fmaxf(__fadd_rn(a.sum[at], b), 0.0f), 1.0f);
+                    if (a.out.final_f32) a.out.final_f32[at] = f;
+                    if (a.out.u8) a.out.u8[at] = (uint8_t)(int)(f * 255.0f);
+                }
             }
             continue;
         }
+        // rows whose whole +-R window lies inside the image share one weight sum (the table kernel adds the same weights in
+        // the same order for each): 16 loads per tile -- and the s_waitcnt vmcnt(0) in front of their use, which also waits
+        // for the previous tile's stores -- only for the tiles within R of the image's top and bottom
+        if (yg0 >= a.R && yg0 + 31 + a.R < a.H) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            tile[(row * 32 + n) * 3 + ch] = acc[i][r] * winv[min(yg0 + row, a.H - 1)];
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                tile[(row * 32 + n) * 3 + ch] = acc[i][r] * winv_mid;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                tile[(row * 32 + n) * 3 + ch] = acc[i][r] * winv[min(yg0 + row, a.H - 1)];
+            }
+        }
+        // this lane's four float4s of the frame's bg + disk: on their way before the barrier, not behind it (every wave of the
+        // workgroup used to stop at the barrier and THEN start a trip to memory, once per tile)
+        float4 sv[4];
+        const bool combine = a.out.final_f32 || a.out.u8;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 192 + ch * 64 + lane;                  // float4 index into the tile: 24 per row
+            const int row = idx / 24, q4 = idx - row * 24;
+            const int yl = yg0 + row - a.row0;
+            if (T <= 5 && combine && yl >= a.r_begin && yl < a.r_end) sv[it] = *reinterpret_cast<const float4 *>(a.sum + ((size_t)yl * a.W + strip * 32) * 3 + 4 * q4);
         }
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int idx = it * 192 + ch * 64 + lane;                  // float4 index into the tile: 24 per row
+            const int idx = it * 192 + ch * 64 + lane;
             const int row = idx / 24, q4 = idx - row * 24;
             const int yl = yg0 + row - a.row0;
             if (yl < a.r_begin || yl >= a.r_end) continue;
             const float4 b = *reinterpret_cast<const float4 *>(tile + row * 96 + 4 * q4);
             const size_t at = ((size_t)yl * a.W + strip * 32) * 3 + 4 * q4;
             if (a.out.blur) *reinterpret_cast<float4 *>(a.out.blur + at) = b;
-            if (a.out.final_f32 || a.out.u8) {
-                const float4 g = *reinterpret_cast<const float4 *>(a.bg + at), d4 = *reinterpret_cast<const float4 *>(a.disk + at);
+            if (combine) {
+                const float4 s = T <= 5 ? sv[it] : *reinterpret_cast<const float4 *>(a.sum + at);   // (T = 8 has no registers to spare: 2 waves per SIMD)
                 float4 f;
-                f.x = fminf(fmaxf(g.x + d4.x + b.x, 0.0f), 1.0f);
-                f.y = fminf(fmaxf(g.y + d4.y + b.y, 0.0f), 1.0f);
-                f.z = fminf(fmaxf(g.z + d4.z + b.z, 0.0f), 1.0f);
-                f.w = fminf(fmaxf(g.w + d4.w + b.w, 0.0f), 1.0f);
+                f.x = fminf(fmaxf(__fadd_rn(s.x, b.x), 0.0f), 1.0f);
+                f.y = fminf(fmaxf(__fadd_rn(s.y, b.y), 0.0f), 1.0f);
+                f.z = fminf(fmaxf(__fadd_rn(s.z, b.z), 0.0f), 1.0f);
+                f.w = fminf(fmaxf(__fadd_rn(s.w, b.w), 0.0f), 1.0f);
                 if (a.out.final_f32) *reinterpret_cast<float4 *>(a.out.final_f32 + at) = f;
                 if (a.out.u8)
                     *reinterpret_cast<unsigned int *>(a.out.u8 + at) = (unsigned int)(int)(f.x * 255.0f) | ((unsigned int)(int)(f.y * 255.0f) << 8) |
@@ -690,13 +770,33 @@ int32_t allow_lds(const void *fn, size_t bytes) {
     return BHR_OK;
 }
 
-// Output tiles per wave.  More tiles per wave = fewer re-reads of the chunks between them (a wave of s tiles walks 2 s + 2 NT - 1
-// chunks) but fewer waves; the passes are bound by memory latency until the chip holds ~4 waves per SIMD: as many tiles per
-// wave as still leave `tiles_total x 3 channels / s` >= 4096 waves, at least 1, at most 8.  s <= 4 runs the T = 4
-// instantiation (3 waves per SIMD by registers), larger s the T = 8 one (2).
-int pick_tiles(long long tiles_total) {
-    int s = (int)(tiles_total * 3 / 4096);
-    return s < 1 ? 1 : (s > 8 ? 8 : s);
+// How a launch is cut: `n_tiles` output tiles per row (H) / column (V), `others` such rows / columns, three channel waves per
+// unit, two units per workgroup.  Two instantiations: T = 5 tiles per wave at 3 waves per SIMD (two workgroups per CU: rounds
+// of 512 workgroups) and T = 8 at 2 (one per CU: rounds of 256).  A round lasts about as long as its longest wave, and a
+// wave of s tiles costs ~ s tiles + (2 s + 2 NT) chunk loads + a fixed part (table staging, barriers): the (T, segment count)
+// with the cheapest rounds x wave.  (Measured first with fixed tile counts: an 8k row block's 540-workgroup passes took
+// THREE rounds of one-per-CU workgroups.)
+struct SplitPlan { int T, n_seg, seg; };
+SplitPlan plan_segments(int n_tiles, long long others, int NT, int forced_tiles) {
+    if (forced_tiles > 0) {
+        const int sf = min(min(forced_tiles, 8), n_tiles);
+        return SplitPlan{sf > 5 ? 8 : 5, (n_tiles + sf - 1) / sf, sf};
+    }
+    SplitPlan best{5, n_tiles, 1};
+    double best_cost = 1e300;
+    long long best_rounds = 1;
+    for (int n_seg = (n_tiles + 4) / 5; n_seg <= n_tiles; ++n_seg) {
+        const int sg = (n_tiles + n_seg - 1) / n_seg;
+        const long long groups = (others * ((n_tiles + sg - 1) / sg) + SPLIT_SUBS - 1) / SPLIT_SUBS;
+        const long long rounds = (groups + 511) / 512;
+        const double cost = (double)rounds * (1.0 * sg + 0.04 * (2 * sg + 2 * NT) + 1.5);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = SplitPlan{5, (n_tiles + sg - 1) / sg, sg}; best_rounds = rounds; }
+    }
+    // many rounds: the whole 8k frame.  Eight tiles per wave halve the chunk re-reads (measured 0.75 against 0.81 ms there;
+    // the T = 8 instantiation loses everywhere else: 4k 0.21 against 0.18, an 8k row block 0.21 against 0.13).  (Five tiles
+    // rather than four in the small one: an 8k row block's 17 stacked tiles cut 5 + 4 + 4 + 4 fill ONE round of workgroups.)
+    if (best_rounds >= 6 && n_tiles >= 8) return SplitPlan{8, (n_tiles + 7) / 8, 8};
+    return best;
 }
 
 }  // namespace
@@ -750,8 +850,9 @@ int32_t bhr_launch_bloom_pack(bhr_ctx *ctx) {
     bhr_split_geometry(ctx, &g);
     const int groups = (ctx->cfg.width + 7) / 8;
     hipLaunchKernelGGL(bloom_pack_kernel, dim3((groups + 63) / 64, ctx->rows), dim3(64), 0, ctx->stream, ctx->d_disk,
-                       (_Float16 *)ctx->d_pa, ctx->cfg.width, ctx->rows, g.YB, g.GP, g.g0);
+                       ctx->d_bg, ctx->d_sum, (_Float16 *)ctx->d_pa, ctx->cfg.width, ctx->rows, g.YB, g.GP, g.g0);
     BHR_HIP(hipGetLastError());
+    ctx->slots[ctx->active_slot].sum_valid = 1;
     return BHR_OK;
 }
 
@@ -780,11 +881,12 @@ int32_t bhr_launch_bloom_h(bhr_ctx *ctx) {
         }
         if (ctx->n_mirrors > MAX_MIRRORS) return bhr_fail(BHR_ERR_INVALID, "bloom H: %d mirror planes (at most %d)", ctx->n_mirrors, MAX_MIRRORS);
         a.dbg = ctx->opt.bloom_dbg & 15;
-        a.seg = ctx->opt.bloom_tiles > 0 ? ctx->opt.bloom_tiles : pick_tiles((long long)g.n_tx * g.YB);
-        const int T = a.seg > 4 ? 8 : 4;
-        dim3 grid((g.n_tx + a.seg - 1) / a.seg, (g.YB + SPLIT_SUBS - 1) / SPLIT_SUBS), block(SPLIT_THREADS);
-        if (T == 8) { BHR_TRY(allow_lds((const void *)bloom_h_split_kernel<8>, g.table_bytes)); hipLaunchKernelGGL(bloom_h_split_kernel<8>, grid, block, g.table_bytes, ctx->stream, a); }
-        else { BHR_TRY(allow_lds((const void *)bloom_h_split_kernel<4>, g.table_bytes)); hipLaunchKernelGGL(bloom_h_split_kernel<4>, grid, block, g.table_bytes, ctx->stream, a); }
+        const SplitPlan pl = plan_segments(g.n_tx, g.YB, g.NT, ctx->opt.bloom_tiles);
+        a.seg = pl.seg;
+        a.n_seg = pl.n_seg;
+        dim3 grid(((long long)a.n_seg * g.YB + SPLIT_SUBS - 1) / SPLIT_SUBS), block(SPLIT_THREADS);
+        if (pl.T == 8) { BHR_TRY(allow_lds((const void *)bloom_h_split_kernel<8>, g.table_bytes)); hipLaunchKernelGGL(bloom_h_split_kernel<8>, grid, block, g.table_bytes, ctx->stream, a); }
+        else { BHR_TRY(allow_lds((const void *)bloom_h_split_kernel<5>, g.table_bytes)); hipLaunchKernelGGL(bloom_h_split_kernel<5>, grid, block, g.table_bytes, ctx->stream, a); }
         BHR_HIP(hipGetLastError());
         return BHR_OK;
     }
@@ -819,23 +921,30 @@ int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, in
         a.pb = (const _Float16 *)ctx->d_pb;
         a.w16 = ctx->d_w16;
         a.wsum_v = ctx->d_wsum_v;
-        a.bg = ctx->d_bg; a.disk = ctx->d_disk;
+        if (!ctx->slots[ctx->active_slot].sum_valid) {          // layers the caller wrote after the march (bhr_write_layer)
+            const long long n = (long long)ctx->rows * W * 3;
+            hipLaunchKernelGGL(bloom_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_bg, ctx->d_disk, ctx->d_sum, n);
+            BHR_HIP(hipGetLastError());
+            ctx->slots[ctx->active_slot].sum_valid = 1;
+        }
+        a.sum = ctx->d_sum;
         a.out = out;
         a.zero_cell = ctx->v_zero_cell;
         a.W = W; a.WP = g.WP; a.H = H; a.row0 = ctx->cfg.row0;
         a.GR = g.GR; a.t_first = g.t_first;
-        a.NT = g.NT; a.table_bytes = g.table_bytes;
+        a.NT = g.NT; a.table_bytes = g.table_bytes; a.R = R;
         a.seg_t0 = (ctx->cfg.row0 + r0) / 32 - g.t_first;
         a.seg_t1 = (ctx->cfg.row0 + r1 - 1) / 32 - g.t_first + 1;
         a.r_begin = r0; a.r_end = r1;
         const int nt = a.seg_t1 - a.seg_t0;
         a.dbg = (ctx->opt.bloom_dbg >> 4) & 15;
-        a.seg = ctx->opt.bloom_tiles > 0 ? ctx->opt.bloom_tiles : pick_tiles((long long)nt * g.n_tx);
-        const int T = a.seg > 4 ? 8 : 4;
-        dim3 grid((g.n_tx + SPLIT_SUBS - 1) / SPLIT_SUBS, (nt + a.seg - 1) / a.seg), block(SPLIT_THREADS);
+        const SplitPlan pl = plan_segments(nt, g.n_tx, g.NT, ctx->opt.bloom_tiles);
+        a.seg = pl.seg;
+        a.n_seg = pl.n_seg;
+        dim3 grid(((long long)a.n_seg * g.n_tx + SPLIT_SUBS - 1) / SPLIT_SUBS), block(SPLIT_THREADS);
         const size_t lds = (size_t)g.table_bytes + SPLIT_SUBS * 32 * 96 * sizeof(float);     // table + one [32][32][3] tile per strip
-        if (T == 8) { BHR_TRY(allow_lds((const void *)bloom_v_split_kernel<8>, lds)); hipLaunchKernelGGL(bloom_v_split_kernel<8>, grid, block, lds, ctx->stream, a); }
-        else { BHR_TRY(allow_lds((const void *)bloom_v_split_kernel<4>, lds)); hipLaunchKernelGGL(bloom_v_split_kernel<4>, grid, block, lds, ctx->stream, a); }
+        if (pl.T == 8) { BHR_TRY(allow_lds((const void *)bloom_v_split_kernel<8>, lds)); hipLaunchKernelGGL(bloom_v_split_kernel<8>, grid, block, lds, ctx->stream, a); }
+        else { BHR_TRY(allow_lds((const void *)bloom_v_split_kernel<5>, lds)); hipLaunchKernelGGL(bloom_v_split_kernel<5>, grid, block, lds, ctx->stream, a); }
         BHR_HIP(hipGetLastError());
         return BHR_OK;
     }

@@ -301,6 +301,7 @@ int32_t render_tiles(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flag
         c->last_slot = -1;
         BHR_TRY(ensure_pipe(c));
         BHR_TRY(bhr_frame_begin(c, flags));
+        c->group_time_march = (flags & BHR_GROUP_TIME_MARCH) ? 1 : 0;
     }
     const bool halo = with_bloom && n > 1;
     if (halo)
@@ -314,7 +315,10 @@ int32_t render_tiles(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flag
         TilePipe *p = (TilePipe *)c->pipe;
         BHR_TRY(bhr_launch_march(c, cam, flags));
         if (with_bloom) BHR_TRY(bhr_launch_bloom_h(c));
-        BHR_HIP(hipEventRecord(p->halo_ready, c->stream));
+        // `halo_ready` (this tile's H pass is done: its neighbours may run the V pass of their edge rows).  An event record is a
+        // ~5 us bubble in the stream: the pipelined schedule records it BEHIND the V pass of the middle rows (phase 3) -- the
+        // neighbours are busy with their own middle rows until then -- the serial one here
+        if (!pipelined || !with_bloom || !c->bloom_split) BHR_HIP(hipEventRecord(p->halo_ready, c->stream));
         return BHR_OK;
     }));
     for (int k = 0; k < n; ++k)
@@ -333,40 +337,49 @@ int32_t render_tiles(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flag
             BHR_HIP(hipEventRecord(p->halo_in, s));
         }
 
-    // phase 3: V pass + combine, storing straight into the frame buffers on tile 0's device where it may
-    for (int k = 0; k < n; ++k) {
-        if (live && !live[k]) continue;
-        bhr_ctx *c = ctxs[k];
-        TilePipe *p = (TilePipe *)c->pipe;
-        BHR_HIP(hipSetDevice(c->cfg.device));
-        const bool direct = gather && !flare && !out_host && peer_ok(c, head);
-        uint32_t want = 0;
-        if (direct) want = ((flags & BHR_GATHER_U8) ? BHR_OUT_U8 : 0u) | ((flags & BHR_GATHER_PEER) ? BHR_OUT_F32 : 0u);
-        else want = BHR_OUT_F32 | ((gather && !flare && (flags & BHR_GATHER_U8)) ? BHR_OUT_U8 : 0u);
-        Chunk chunks[PIPE_MAX_CHUNKS];
-        const int n_chunks = plan_chunks(c, halo && k > 0, halo && k < n - 1, bhr_bloom_v_tile_rows(c), pipelined, chunks);
-        bool waited = false;
-        auto wait_halo = [&]() -> int32_t {
-            if (waited || !halo) return BHR_OK;
-            waited = true;
-            if (!c->bloom_split) { BHR_HIP(hipStreamWaitEvent(c->stream, p->halo_in, 0)); return BHR_OK; }
-            const int reach = 16 * (bhr_split_nt(c->bloom_R) - 1) + 32;
-            for (int q = 0; q < n; ++q) {
-                if (q == k || (live && !live[q]) || !needs_rows_of(c, ctxs[q], reach)) continue;
-                BHR_HIP(hipStreamWaitEvent(c->stream, ((TilePipe *)ctxs[q]->pipe)->halo_ready, 0));
+    // phase 3: V pass + combine, storing straight into the frame buffers on tile 0's device where it may.  Two host passes
+    // over the tiles: (a) the chunks that need no halo rows, then `halo_ready` where it is still to be recorded; (b) the wait
+    // for the neighbours and the chunks next to the edges -- every event a tile waits for has been recorded for THIS frame
+    // by then.
+    for (int pass = 0; pass < 2; ++pass)
+        for (int k = 0; k < n; ++k) {
+            if (live && !live[k]) continue;
+            bhr_ctx *c = ctxs[k];
+            TilePipe *p = (TilePipe *)c->pipe;
+            BHR_HIP(hipSetDevice(c->cfg.device));
+            const bool direct = gather && !flare && !out_host && peer_ok(c, head);
+            uint32_t want = 0;
+            if (direct) want = ((flags & BHR_GATHER_U8) ? BHR_OUT_U8 : 0u) | ((flags & BHR_GATHER_PEER) ? BHR_OUT_F32 : 0u);
+            else want = BHR_OUT_F32 | ((gather && !flare && (flags & BHR_GATHER_U8)) ? BHR_OUT_U8 : 0u);
+            Chunk chunks[PIPE_MAX_CHUNKS];
+            const int n_chunks = plan_chunks(c, halo && k > 0, halo && k < n - 1, bhr_bloom_v_tile_rows(c), pipelined, chunks);
+            if (pass == 0) {
+                for (int ci = 0; ci < n_chunks; ++ci)
+                    if (!chunks[ci].needs_halo)
+                        BHR_TRY(bhr_launch_bloom_v_rows(c, with_bloom, chunks[ci].r0, chunks[ci].r1, want, direct ? head->d_gather_u8 : nullptr,
+                                                        direct ? head->d_gather : nullptr));
+                if (pipelined && with_bloom && c->bloom_split) BHR_HIP(hipEventRecord(p->halo_ready, c->stream));
+                continue;
             }
-            return BHR_OK;
-        };
-        for (int ci = 0; ci < n_chunks; ++ci) {
-            if (chunks[ci].needs_halo) BHR_TRY(wait_halo());
-            BHR_TRY(bhr_launch_bloom_v_rows(c, with_bloom, chunks[ci].r0, chunks[ci].r1, want, direct ? head->d_gather_u8 : nullptr,
-                                            direct ? head->d_gather : nullptr));
+            if (halo) {
+                if (!c->bloom_split) {
+                    BHR_HIP(hipStreamWaitEvent(c->stream, p->halo_in, 0));
+                } else {
+                    const int reach = 16 * (bhr_split_nt(c->bloom_R) - 1) + 32;
+                    for (int q = 0; q < n; ++q) {
+                        if (q == k || (live && !live[q]) || !needs_rows_of(c, ctxs[q], reach)) continue;
+                        BHR_HIP(hipStreamWaitEvent(c->stream, ((TilePipe *)ctxs[q]->pipe)->halo_ready, 0));
+                    }
+                }
+            }
+            for (int ci = 0; ci < n_chunks; ++ci)
+                if (chunks[ci].needs_halo)
+                    BHR_TRY(bhr_launch_bloom_v_rows(c, with_bloom, chunks[ci].r0, chunks[ci].r1, want, direct ? head->d_gather_u8 : nullptr,
+                                                    direct ? head->d_gather : nullptr));
+            c->slots[c->active_slot].have = direct ? 0u : want;           // what sits in the tile's OWN buffers
+            c->last_flags = (int32_t)flags;
+            c->timing_valid = 1;
         }
-        BHR_TRY(wait_halo());                                         // nothing of this frame stays in flight
-        c->slots[c->active_slot].have = direct ? 0u : want;           // what sits in the tile's OWN buffers
-        c->last_flags = (int32_t)flags;
-        c->timing_valid = 1;
-    }
     if (flare) BHR_TRY(flare_pass(ctxs, n, live));
     if (gather)
         for (int k = 0; k < n; ++k) {
@@ -591,6 +604,7 @@ int32_t tile_render_linked(bhr_ctx *ctx, TilePipe *p, const bhr_camera *cam, uin
     ctx->cur_slot = -1;
     ctx->last_slot = -1;
     BHR_TRY(bhr_frame_begin(ctx, flags));
+    ctx->group_time_march = (flags & BHR_GROUP_TIME_MARCH) ? 1 : 0;
     if (with_bloom && ctx->bloom_split != p->split)
         return bhr_fail(BHR_ERR_INVALID, "bhr_tile_render: the flags select the other post-pass arithmetic than the one the tiles were connected for");
     const bool halo = with_bloom && world > 1;

@@ -36,12 +36,21 @@ struct FixList {           // per frame slot: pixels the fast list's guard kerne
     int32_t cap;
 };
 
+constexpr int LIST_RING = 4;
 struct SlotLists {
     int32_t *d_list;       // the base list partitioned: strict tiles first (launch order kept), then the fast ones
     int32_t *h_pinned;
     hipEvent_t copied;     // the last upload from h_pinned
     double key[12];
     int32_t n_strict, base_n, valid, pending;
+    // device classification: a partition is written on the classification stream while the slot's earlier frames may still
+    // march over the previous one -- four buffers in turn, each guarded by the event of the last march that read it
+    int32_t *d_ring[LIST_RING];
+    hipEvent_t used[LIST_RING];
+    int32_t used_set[LIST_RING];
+    int32_t cur;           // ring entry the slot marches over, -1 none yet
+    int32_t on_device;     // which of the two paths made the list in use
+    const int32_t *d_active;
 };
 
 struct Hybrid {
@@ -50,10 +59,15 @@ struct Hybrid {
     // last classification on the host
     std::vector<uint8_t> strict;   // per tile of the row block: marched strict
     double key[12];
-    int32_t n_strict, valid;
+    int32_t n_strict, valid, n_tiles, on_device;
     double lo, hi;                 // band below / above b_c (BHR_HYBRID_BAND="lo,hi")
     double eff_lo, eff_hi;         // ... as the last march used it (widened with the step size beyond 0.1)
     int32_t last_fix_slot;         // frame slot whose fix list the last march used, -1: it ran without guards
+    // device classification
+    hipStream_t cls_stream;
+    uint8_t *d_flags;
+    int32_t *d_counts, *d_total, *h_total;
+    int32_t n_tiles_alloc;
 };
 
 void view_key(const bhr_camera *cam, double lo, double hi, double tilt_deg, double key[12]) {
@@ -183,6 +197,141 @@ void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, s
         }
 }
 
+
+// ---- the same classification on the device (round 4) -------------------------------------------------------------------
+// `classify` above is O(tiles) of binary64 work on the submitting thread -- 32 400 tiles at fhd, 518 400 at 8k (50 ms) -- and
+// the partition of the launch order behind it another pass over every tile: fine for an orbit at constant radius (cached),
+// a stall in front of every frame of a camera path that changes its distance.  Here every tile evaluates the same rule, the
+// same operations in the same order (no FMA contraction in this file), in a kernel; the stable partition of the launch order
+// is three small kernels (per-block counts, scan of the counts, scatter); all of it runs on a stream of its own, the host
+// waits for the strict count alone (it sizes the two march launches): ~40 us per view change whatever the resolution.
+struct ClassifyArgs {
+    double cp[3], cr[3], cu[3], tl[3], nrm[3];
+    double pw, ph, r0sq, cpn, lo, hi;
+    int32_t W, rows, row0, tiles_x, tiles_y, far_cam;
+};
+
+struct Corner { float b, s, bl; int32_t bits; };   // bits: 1 leaves the camera above the disk plane, 2 outgoing
+
+// one corner of the tile grid: the body of classify's first loop, operation for operation
+__device__ __forceinline__ Corner classify_corner(const ClassifyArgs &a, int gx, int gy) {
+#pragma clang fp contract(off)
+    const double y = (double)a.row0 + (double)(gy * 8 < a.rows ? gy * 8 : a.rows) - 0.5;
+    const double x = (double)(gx * 8 < a.W ? gx * 8 : a.W) - 0.5;
+    double d[3], dn = 0, pd = 0;
+    for (int k = 0; k < 3; ++k) {
+        d[k] = a.tl[k] + (x + 0.5) * a.pw * a.cr[k] - (y + 0.5) * a.ph * a.cu[k] - a.cp[k];
+        dn += d[k] * d[k];
+        pd += a.cp[k] * d[k];
+    }
+    pd /= sqrt(dn);
+    const double inv_d = 1.0 / sqrt(dn);
+    double dnn = 0, v2 = 0;
+    for (int k = 0; k < 3; ++k) dnn += d[k] * inv_d * a.nrm[k];
+    for (int k = 0; k < 3; ++k) { const double v = d[k] * inv_d * a.cpn - a.cp[k] * dnn; v2 += v * v; }
+    const double bl = sqrt(a.r0sq - pd * pd > 1e-18 ? a.r0sq - pd * pd : 1e-18);
+    Corner c;
+    c.s = (float)(sqrt(v2) / bl);
+    c.bl = (float)bl;
+    const double bl2 = a.r0sq - pd * pd;
+    const double inv = (bl2 > 1e-12 ? 1.0 / bl2 : 1e12) - 1.0 / (a.r0sq * sqrt(a.r0sq));
+    c.b = (float)(inv > 1e-6 ? 1.0 / sqrt(inv) : 1e3);
+    c.bits = (dnn > 0 ? 1 : 0) | (pd > 0 ? 2 : 0);
+    return c;
+}
+
+constexpr int CLS_EDGE = 16;     // a workgroup classifies 16 x 16 tiles from their 17 x 17 corners (each evaluated once, through LDS)
+__global__ __launch_bounds__(CLS_EDGE * CLS_EDGE) void hybrid_classify_kernel(ClassifyArgs a, uint8_t *__restrict__ flags, int32_t *__restrict__ total_all) {
+#pragma clang fp contract(off)
+    __shared__ Corner cs[(CLS_EDGE + 1) * (CLS_EDGE + 1)];
+    const int bx = blockIdx.x * CLS_EDGE, by = blockIdx.y * CLS_EDGE;
+    for (int k = threadIdx.x; k < (CLS_EDGE + 1) * (CLS_EDGE + 1); k += CLS_EDGE * CLS_EDGE) {
+        const int gx = bx + k % (CLS_EDGE + 1), gy = by + k / (CLS_EDGE + 1);
+        if (gx <= a.tiles_x && gy <= a.tiles_y) cs[k] = classify_corner(a, gx, gy);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % CLS_EDGE, ly = threadIdx.x / CLS_EDGE;
+    const int tx = bx + lx, ty = by + ly;
+    int f = 0;
+    const bool live = tx < a.tiles_x && ty < a.tiles_y;
+    if (live) {
+        const Corner c[4] = {cs[ly * (CLS_EDGE + 1) + lx], cs[ly * (CLS_EDGE + 1) + lx + 1], cs[(ly + 1) * (CLS_EDGE + 1) + lx], cs[(ly + 1) * (CLS_EDGE + 1) + lx + 1]};
+        float bmin = c[0].b, bmax = c[0].b, smin = c[0].s, blmax = c[0].bl;
+        int ups = 0, outs = 0;
+        for (int k = 0; k < 4; ++k) {
+            bmin = c[k].b < bmin ? c[k].b : bmin;
+            bmax = c[k].b > bmax ? c[k].b : bmax;
+            smin = c[k].s < smin ? c[k].s : smin;
+            blmax = c[k].bl > blmax ? c[k].bl : blmax;
+            ups += c[k].bits & 1;
+            outs += (c[k].bits >> 1) & 1;
+        }
+        if (fabs(a.cpn) < PLANE_SIN * (double)blmax && ((ups != 0 && ups != 4) || (double)smin < 1.5 * PLANE_SIN)) f = 1;
+        else if (a.far_cam && outs == 4) f = 0;
+        else {
+            const double pad = (double)(bmax - bmin) + 1e-3;
+            f = (bmax + pad >= B_CRIT - a.lo && bmin - pad <= B_CRIT + a.hi) ? 1 : 0;
+        }
+        flags[(size_t)ty * a.tiles_x + tx] = (uint8_t)f;
+    }
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(total_all, __popcll(m));
+}
+
+constexpr int PART_BLOCK = 256;
+// counts[b] = strict tiles among launch-order positions [256 b, 256 b + 256)
+__global__ __launch_bounds__(PART_BLOCK) void hybrid_count_kernel(const int32_t *__restrict__ order, int n, const uint8_t *__restrict__ flags,
+                                                                   int32_t *__restrict__ counts) {
+    __shared__ int wave_n[PART_BLOCK / 64];
+    const int pos = blockIdx.x * PART_BLOCK + threadIdx.x;
+    const int f = pos < n ? flags[order[pos]] : 0;
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wave_n[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+}
+// exclusive scan of counts[0 .. nb) in place (one workgroup); the list's strict count -> *total and, with the frame's, -> pinned host memory
+__global__ __launch_bounds__(1024) void hybrid_scan_kernel(int32_t *__restrict__ counts, int nb, int32_t *__restrict__ total, const int32_t *__restrict__ total_all,
+                                                            int32_t *__restrict__ total_host) {
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int k = base + threadIdx.x;
+        const int v = k < nb ? counts[k] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {              // Hillis-Steele: 10 steps per 1024 counts
+            const int t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (k < nb) counts[k] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *total = carry; total_host[0] = carry; total_host[1] = *total_all; }
+}
+// stable partition of the launch order: strict tiles first, then the fast ones, both in launch order
+__global__ __launch_bounds__(PART_BLOCK) void hybrid_scatter_kernel(const int32_t *__restrict__ order, int n, const uint8_t *__restrict__ flags,
+                                                                     const int32_t *__restrict__ offsets, const int32_t *__restrict__ total,
+                                                                     int32_t *__restrict__ out) {
+    __shared__ int wave_n[PART_BLOCK / 64];
+    const int pos = blockIdx.x * PART_BLOCK + threadIdx.x;
+    int tile = 0, f = 0;
+    if (pos < n) { tile = order[pos]; f = flags[tile]; }
+    const unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wave_n[w] = __popcll(m);
+    __syncthreads();
+    int before = offsets[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+    for (int q = 0; q < w; ++q) before += wave_n[q];
+    if (pos < n) out[f ? before : *total + (pos - before)] = tile;
+}
+
 }  // namespace
 
 void bhr_hybrid_free(bhr_ctx *ctx) {
@@ -198,8 +347,28 @@ void bhr_hybrid_free(bhr_ctx *ctx) {
         if (f.d_count) (void)hipFree(f.d_count);
         if (f.d_list) (void)hipFree(f.d_list);
     }
+    for (auto &row : h->slot)
+        for (auto &sl : row)
+            for (int k = 0; k < LIST_RING; ++k) {
+                if (sl.d_ring[k]) (void)hipFree(sl.d_ring[k]);
+                if (sl.used[k]) (void)hipEventDestroy(sl.used[k]);
+            }
+    if (h->cls_stream) { (void)hipStreamSynchronize(h->cls_stream); (void)hipStreamDestroy(h->cls_stream); }
+    if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->d_counts) (void)hipFree(h->d_counts);
+    if (h->d_total) (void)hipFree(h->d_total);
+    if (h->h_total) (void)hipHostFree(h->h_total);
     delete h;
     ctx->hybrid = nullptr;
+}
+
+int32_t bhr_hybrid_active_list(bhr_ctx *ctx, const int32_t **list, int32_t *n) {
+    Hybrid *h = (Hybrid *)ctx->hybrid;
+    const int k = ctx->active_slot >= 0 && ctx->active_slot < BHR_MAX_FRAME_SLOTS ? ctx->active_slot : 0;
+    if (!h || !h->slot[k][0].valid || !h->slot[k][0].d_active) return bhr_fail(BHR_ERR_STATE, "no hybrid march has run on this context's active slot");
+    *list = h->slot[k][0].d_active;
+    *n = h->slot[k][0].base_n;
+    return BHR_OK;
 }
 
 extern "C" int32_t bhr_hybrid_info(bhr_ctx *ctx, int32_t out_tiles[2], double out_band[2]) {
@@ -207,7 +376,7 @@ extern "C" int32_t bhr_hybrid_info(bhr_ctx *ctx, int32_t out_tiles[2], double ou
     Hybrid *h = (Hybrid *)ctx->hybrid;
     if (!h || !h->valid) return bhr_fail(BHR_ERR_STATE, "bhr_hybrid_info: no hybrid march has run on this context");
     out_tiles[0] = h->n_strict;
-    out_tiles[1] = (int32_t)h->strict.size();
+    out_tiles[1] = h->n_tiles;
     out_band[0] = h->eff_lo;
     out_band[1] = h->eff_hi;
     return BHR_OK;
@@ -238,7 +407,15 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     if (!h) {
         h = new Hybrid();
         memset(h->slot, 0, sizeof(h->slot));
+        for (auto &row : h->slot)
+            for (auto &sl : row) sl.cur = -1;
+        h->n_tiles = 0;
+        h->on_device = -1;
         memset(h->fix, 0, sizeof(h->fix));
+        h->cls_stream = nullptr;
+        h->d_flags = nullptr;
+        h->d_counts = h->d_total = h->h_total = nullptr;
+        h->n_tiles_alloc = 0;
         h->valid = 0;
         h->n_strict = 0;
         h->last_fix_slot = -1;
@@ -262,36 +439,117 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     h->eff_lo = lo;
     h->eff_hi = hi;
     view_key(cam, lo, hi, (double)ctx->cfg.disk_tilt_deg, key);
-    if (!h->valid || !same_view(h->key, key)) {
-        classify(ctx, cam, lo, hi, h->strict);
-        int n = 0;
-        for (int k = 0; k < ctx->tile_order_n; ++k) n += h->strict[(size_t)k];
-        h->n_strict = n;
-        memcpy(h->key, key, sizeof(key));
-        h->valid = 1;
-    }
+    const int n_tiles = ctx->tile_order_n;
+    const bool on_device = ctx->opt.hybrid_classify != 0;
     SlotLists &s = h->slot[ctx->active_slot >= 0 && ctx->active_slot < BHR_MAX_FRAME_SLOTS ? ctx->active_slot : 0][id];
-    if (!s.d_list) {
-        BHR_HIP(hipMalloc((void **)&s.d_list, (size_t)ctx->tile_order_n * sizeof(int32_t)));
-        BHR_HIP(hipHostMalloc((void **)&s.h_pinned, (size_t)ctx->tile_order_n * sizeof(int32_t), hipHostMallocDefault));
-        BHR_HIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
-    }
-    if (!s.valid || s.base_n != base_n || memcmp(s.key, h->key, sizeof(s.key)) != 0) {
-        // the slot's stream is in order: the upload lands behind the slot's previous march; the pinned source is free
-        // once its previous upload has completed
-        if (s.pending) BHR_HIP(hipEventSynchronize(s.copied));
-        int n = 0;                                   // stable partition: the launch order is kept inside both halves
-        for (int k = 0; k < base_n; ++k)
-            if (h->strict[(size_t)base_list[k]]) s.h_pinned[n++] = base_list[k];
-        s.n_strict = n;
-        for (int k = 0; k < base_n; ++k)
-            if (!h->strict[(size_t)base_list[k]]) s.h_pinned[n++] = base_list[k];
-        BHR_HIP(hipMemcpyAsync(s.d_list, s.h_pinned, (size_t)base_n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        BHR_HIP(hipEventRecord(s.copied, ctx->stream));
-        s.pending = 1;
-        memcpy(s.key, h->key, sizeof(s.key));
-        s.base_n = base_n;
-        s.valid = 1;
+    const bool new_view = !h->valid || h->on_device != (int32_t)on_device || !same_view(h->key, key);
+    if (on_device) {
+        const int32_t *d_base = base.active ? base.d_list : ctx->d_tile_order;
+        if (!d_base) return bhr_fail(BHR_ERR_INVALID, "hybrid march: the base list has no device copy");
+        if (!h->cls_stream) {
+            BHR_HIP(hipStreamCreateWithFlags(&h->cls_stream, hipStreamNonBlocking));
+            BHR_HIP(hipMalloc((void **)&h->d_flags, (size_t)n_tiles));
+            BHR_HIP(hipMalloc((void **)&h->d_counts, (size_t)((n_tiles + PART_BLOCK - 1) / PART_BLOCK + 1) * sizeof(int32_t)));
+            BHR_HIP(hipMalloc((void **)&h->d_total, 2 * sizeof(int32_t)));
+            BHR_HIP(hipHostMalloc((void **)&h->h_total, 2 * sizeof(int32_t), hipHostMallocDefault));
+            h->n_tiles_alloc = n_tiles;
+        }
+        if (h->n_tiles_alloc != n_tiles) return bhr_fail(BHR_ERR_STATE, "hybrid march: the tile grid changed under a live context");
+        const bool new_list = new_view || !s.valid || s.base_n != base_n || s.on_device != 1 || memcmp(s.key, h->key, sizeof(s.key)) != 0;
+        if (new_list) {
+            // every march that reads the list this slot used so far has been submitted: its buffer is free once the slot's
+            // stream has passed this point.  The next buffer of the ring was released that way three view changes ago.
+            if (s.cur >= 0) {
+                BHR_HIP(hipEventRecord(s.used[s.cur], ctx->stream));
+                s.used_set[s.cur] = 1;
+            }
+            const int nxt = (s.cur + 1) % LIST_RING;
+            if (!s.d_ring[nxt]) {
+                BHR_HIP(hipMalloc((void **)&s.d_ring[nxt], (size_t)n_tiles * sizeof(int32_t)));
+                BHR_HIP(hipEventCreateWithFlags(&s.used[nxt], hipEventDisableTiming));
+            }
+            if (s.used_set[nxt]) BHR_HIP(hipStreamWaitEvent(h->cls_stream, s.used[nxt], 0));
+            if (new_view) {
+                ClassifyArgs ca;
+                const int W = ctx->cfg.width, H = ctx->cfg.height;
+                double cf[3];
+                for (int k = 0; k < 3; ++k) { ca.cp[k] = cam->pos[k]; ca.cr[k] = cam->right[k]; ca.cu[k] = cam->up[k]; cf[k] = cam->forward[k]; }
+                ca.pw = cam->pixel_width; ca.ph = cam->pixel_height;
+                const double half_w = ca.pw * W / 2, half_h = ca.ph * H / 2;
+                for (int k = 0; k < 3; ++k) ca.tl[k] = ca.cp[k] + cf[k] - half_w * ca.cr[k] + half_h * ca.cu[k];
+                ca.r0sq = ca.cp[0] * ca.cp[0] + ca.cp[1] * ca.cp[1] + ca.cp[2] * ca.cp[2];
+                const double tilt = (double)ctx->cfg.disk_tilt_deg * 3.14159265358979323846 / 180.0;
+                ca.nrm[0] = 0.0; ca.nrm[1] = -sin(tilt); ca.nrm[2] = cos(tilt);
+                ca.cpn = ca.cp[0] * ca.nrm[0] + ca.cp[1] * ca.nrm[1] + ca.cp[2] * ca.nrm[2];
+                ca.lo = lo; ca.hi = hi;
+                ca.W = W; ca.rows = ctx->rows; ca.row0 = ctx->cfg.row0;
+                ca.tiles_x = (W + 7) / 8; ca.tiles_y = (ctx->rows + 7) / 8;
+                ca.far_cam = ca.r0sq > 9.0;
+                if ((long long)ca.tiles_x * ca.tiles_y != n_tiles) return bhr_fail(BHR_ERR_STATE, "hybrid march: %d x %d tiles, launch order of %d", ca.tiles_x, ca.tiles_y, n_tiles);
+                BHR_HIP(hipMemsetAsync(h->d_total + 1, 0, sizeof(int32_t), h->cls_stream));
+                hipLaunchKernelGGL(hybrid_classify_kernel, dim3((ca.tiles_x + CLS_EDGE - 1) / CLS_EDGE, (ca.tiles_y + CLS_EDGE - 1) / CLS_EDGE), dim3(CLS_EDGE * CLS_EDGE), 0,
+                                   h->cls_stream, ca, h->d_flags, h->d_total + 1);
+            }
+            const int nb = (base_n + PART_BLOCK - 1) / PART_BLOCK;
+            if (nb > 0) {
+                hipLaunchKernelGGL(hybrid_count_kernel, dim3(nb), dim3(PART_BLOCK), 0, h->cls_stream, d_base, base_n, h->d_flags, h->d_counts);
+                hipLaunchKernelGGL(hybrid_scan_kernel, dim3(1), dim3(1024), 0, h->cls_stream, h->d_counts, nb, h->d_total, h->d_total + 1, h->h_total);
+                hipLaunchKernelGGL(hybrid_scatter_kernel, dim3(nb), dim3(PART_BLOCK), 0, h->cls_stream, d_base, base_n, h->d_flags, h->d_counts, h->d_total, s.d_ring[nxt]);
+                BHR_HIP(hipGetLastError());
+                // the one host wait of a view change: the strict count sizes the two launches (the lists themselves stay on the device)
+                BHR_HIP(hipStreamSynchronize(h->cls_stream));
+                s.n_strict = h->h_total[0];
+                if (new_view) h->n_strict = h->h_total[1];
+            } else {
+                s.n_strict = 0;
+            }
+            if (s.n_strict < 0 || s.n_strict > base_n) return bhr_fail(BHR_ERR_HIP, "hybrid march: the partition counted %d strict tiles of %d", s.n_strict, base_n);
+            s.cur = nxt;
+            s.d_active = s.d_ring[nxt];
+            memcpy(h->key, key, sizeof(key));
+            h->valid = 1;
+            h->on_device = 1;
+            h->n_tiles = n_tiles;
+            memcpy(s.key, h->key, sizeof(s.key));
+            s.base_n = base_n;
+            s.valid = 1;
+            s.on_device = 1;
+        }
+    } else {
+        if (new_view) {
+            classify(ctx, cam, lo, hi, h->strict);
+            int n = 0;
+            for (int k = 0; k < ctx->tile_order_n; ++k) n += h->strict[(size_t)k];
+            h->n_strict = n;
+            h->n_tiles = n_tiles;
+            memcpy(h->key, key, sizeof(key));
+            h->valid = 1;
+            h->on_device = 0;
+        }
+        if (!s.d_list) {
+            BHR_HIP(hipMalloc((void **)&s.d_list, (size_t)ctx->tile_order_n * sizeof(int32_t)));
+            BHR_HIP(hipHostMalloc((void **)&s.h_pinned, (size_t)ctx->tile_order_n * sizeof(int32_t), hipHostMallocDefault));
+            BHR_HIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        }
+        if (!s.valid || s.base_n != base_n || s.on_device != 0 || memcmp(s.key, h->key, sizeof(s.key)) != 0) {
+            // the slot's stream is in order: the upload lands behind the slot's previous march; the pinned source is free
+            // once its previous upload has completed
+            if (s.pending) BHR_HIP(hipEventSynchronize(s.copied));
+            int n = 0;                                   // stable partition: the launch order is kept inside both halves
+            for (int k = 0; k < base_n; ++k)
+                if (h->strict[(size_t)base_list[k]]) s.h_pinned[n++] = base_list[k];
+            s.n_strict = n;
+            for (int k = 0; k < base_n; ++k)
+                if (!h->strict[(size_t)base_list[k]]) s.h_pinned[n++] = base_list[k];
+            BHR_HIP(hipMemcpyAsync(s.d_list, s.h_pinned, (size_t)base_n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            BHR_HIP(hipEventRecord(s.copied, ctx->stream));
+            s.pending = 1;
+            memcpy(s.key, h->key, sizeof(s.key));
+            s.base_n = base_n;
+            s.valid = 1;
+            s.on_device = 0;
+            s.d_active = s.d_list;
+        }
     }
     const uint32_t f = flags & ~(BHR_FORCE_FAST | BHR_FORCE_STRICT | BHR_FORCE_HYBRID);
     bhr_march_part p;
@@ -305,6 +563,7 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     // The bracket (start event, counter clear / end event) is an empty first / last part on the frame's own stream.
     int streams = ctx->opt.hybrid_streams;           // 2; BHR_HYBRID_STREAMS=1: both lists on the frame's stream
     if (base.active) streams = 1;                    // a pipelined row block already runs its two halves on two streams
+    if (s.n_strict == 0) streams = 1;                // nothing for a second stream to do (row blocks away from the hole's image)
     int32_t rc = BHR_OK;
     // The fast list's kernel carries guards: a lane that comes within a guard band of one of the algorithm's switches -- the
     // truncated mip level, a disk crossing in or next to the terminating step, a step that ends on the disk plane, the
@@ -344,22 +603,27 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     const int first0 = base.active ? base.first : 1, last0 = base.active ? base.last : 1;
     if (streams == 1) {
         // longest rays first: the strict tiles are the ones around the photon ring
-        rc = launch(s.d_list, s.n_strict, first0, 0, 0);
+        rc = launch(s.d_active, s.n_strict, first0, 0, 0);
         if (rc == BHR_OK && repair) rc = hipMemsetAsync(fx.d_count, 0, sizeof(unsigned int), ctx->stream) == hipSuccess ? BHR_OK : bhr_fail(BHR_ERR_HIP, "hipMemsetAsync failed");
-        if (rc == BHR_OK) rc = launch(s.d_list + s.n_strict, base_n - s.n_strict, 0, repair ? 0 : last0, 1);
+        if (rc == BHR_OK) rc = launch(s.d_active + s.n_strict, base_n - s.n_strict, 0, repair ? 0 : last0, 1);
         if (rc == BHR_OK && repair) rc = launch(nullptr, 0, 0, last0, 2);
     } else {
         hipStream_t main_stream = ctx->stream;
         rc = launch(nullptr, 0, 1, 0, 0);                                          // prologue on the frame's stream
         if (rc == BHR_OK) rc = bhr_aux_fork(ctx);
-        if (rc == BHR_OK) rc = launch(s.d_list, s.n_strict, 0, 0, 0);
+        // which list rides the frame's own stream: the one that ends last, so that the post-pass follows it on the same
+        // hardware queue (a wait on another queue's event costs ~10 us after that queue's kernel has ended; on a finished one,
+        // nothing).  That is the fast list -- ten times the tiles of the strict one -- except under option "hybrid_swap" 0.
+        const bool fast_on_main = ctx->opt.hybrid_swap != 0;
+        if (fast_on_main) ctx->stream = ctx->aux_stream;
+        if (rc == BHR_OK) rc = launch(s.d_active, s.n_strict, 0, 0, 0);
         if (rc == BHR_OK) {
-            ctx->stream = ctx->aux_stream;
+            ctx->stream = fast_on_main ? main_stream : ctx->aux_stream;
             if (repair && hipMemsetAsync(fx.d_count, 0, sizeof(unsigned int), ctx->stream) != hipSuccess) rc = bhr_fail(BHR_ERR_HIP, "hipMemsetAsync failed");
-            if (rc == BHR_OK) rc = launch(s.d_list + s.n_strict, base_n - s.n_strict, 0, 0, 1);
+            if (rc == BHR_OK) rc = launch(s.d_active + s.n_strict, base_n - s.n_strict, 0, 0, 1);
             if (rc == BHR_OK && repair) rc = launch(nullptr, 0, 0, 0, 2);
-            ctx->stream = main_stream;
         }
+        ctx->stream = main_stream;
         if (rc == BHR_OK) rc = bhr_aux_join(ctx);
         if (rc == BHR_OK) rc = launch(nullptr, 0, 0, 1, 0);                        // epilogue: the end event
     }

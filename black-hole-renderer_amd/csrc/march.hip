@@ -480,14 +480,20 @@ __device__ __forceinline__ void write_pixel(const BhrMarchArgs &a, int i, int j,
     if (escaped) bg = sample_skybox(a.sc, normalized(esc_dir));
     float k = 1.0f - sh.alpha_total;
     size_t o = ((size_t)j * a.width + i) * 3;
-    a.bg[o + 0] = bg.x * k;
-    a.bg[o + 1] = bg.y * k;
-    a.bg[o + 2] = bg.z * k;
+    const float bk[3] = {__fmul_rn(bg.x, k), __fmul_rn(bg.y, k), __fmul_rn(bg.z, k)};
+    a.bg[o + 0] = bk[0];
+    a.bg[o + 1] = bk[1];
+    a.bg[o + 2] = bk[2];
     const float dk[3] = {fminf(fmaxf(sh.accum.x, 0.0f), 1.0f), fminf(fmaxf(sh.accum.y, 0.0f), 1.0f), fminf(fmaxf(sh.accum.z, 0.0f), 1.0f)};
     a.disk[o + 0] = dk[0];
     a.disk[o + 1] = dk[1];
     a.disk[o + 2] = dk[2];
     if (a.diskp) {
+        // bg + disk as the V pass would form it from the two stored layers (one rounding of the product, one of the sum):
+        // its combine reads 12 bytes per pixel instead of 24
+        a.sum[o + 0] = __fadd_rn(bk[0], dk[0]);
+        a.sum[o + 1] = __fadd_rn(bk[1], dk[1]);
+        a.sum[o + 2] = __fadd_rn(bk[2], dk[2]);
         // The disk layer once more for the split-f16 bloom (bloom.hip): every value x 2^14 cut into two f16 halves (hi =
         // RN16, lo = RN16 of the rest: 24 significant bits between them), laid out [channel][half][32-row block][8-pixel
         // group][row][8 pixels] -- the H pass's MFMA operand order.  The 8x8 tile of a wave is ONE 128-byte line of it per
@@ -1380,13 +1386,16 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     a.disk = ctx->d_disk;
     a.diskp = nullptr;
     a.dp_yb = a.dp_gp = a.dp_g0 = 0;
-    if (ctx->bloom_split && ctx->d_pa && !(flags & BHR_SKIP_BLOOM)) {      // split-f16 post-pass: the march feeds its H pass directly
+    a.sum = nullptr;
+    if (ctx->bloom_split && ctx->d_pa && ctx->d_sum && !(flags & BHR_SKIP_BLOOM)) {      // split-f16 post-pass: the march feeds its H pass directly
         bhr_split_geom g;
         bhr_split_geometry(ctx, &g);
         a.diskp = (_Float16 *)ctx->d_pa;
         a.dp_yb = g.YB;
         a.dp_gp = g.GP;
         a.dp_g0 = g.g0;
+        a.sum = ctx->d_sum;
+        ctx->slots[ctx->active_slot].sum_valid = 1;
     }
     // timed launches (bhr_render) count into their ring slot; group launches into the scalar
     const int slot = ctx->cur_slot;
@@ -1535,7 +1544,10 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
             hipLaunchKernelGGL(march_persistent_kernel<false>, grid, block, 0, ctx->stream, a, refill_below);
     }
     BHR_HIP(hipGetLastError());
-    if (last_part) BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 1] : ctx->ev[1], ctx->stream));
+    // group / tile renders (slot < 0) record the march's end only on request: the event is a ~5 us bubble between the march and
+    // the H pass of a tile whose whole tail is ~0.12 ms
+    if (last_part && (slot >= 0 || ctx->group_time_march)) BHR_HIP(hipEventRecord(slot >= 0 ? ctx->ring_ev[slot * 3 + 1] : ctx->ev[1], ctx->stream));
+    if (last_part) ctx->march_end_recorded = slot >= 0 || ctx->group_time_march;
     if (d_stamps) {
         std::vector<unsigned long long> h((size_t)a.n_tiles * 4);
         BHR_HIP(hipMemcpyAsync(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));

@@ -227,7 +227,7 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
                  fov: float, static_cam_pos: List[float], orbit: bool = False, resume: bool = False,
                  disk_rotation_speed: float = 0.1, orbit_degrees: float = 360.0, rank: int = 0, world: int = 1,
                  assemble: bool = True, png_level: int = DEVICE, sink_slots: int = 0, sink_workers: int = 0,
-                 video_stream: str = "auto", **_deprecated_kwargs) -> None:
+                 video_stream: str = "auto", stats: Optional[dict] = None, **_deprecated_kwargs) -> None:
     """N frames -> PNGs (+ MP4) (render.py:4356-4511).  Frame f is rendered by rank f % world.
 
     ``video_stream``: the reference assembles the MP4 by reading every PNG back (render.py:4497-4503).  Here a
@@ -316,6 +316,7 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
     factories = init_lifecycle_system(renderer, n_r, n_phi, seed=42)
     dt = disk_rotation_speed
     print(f"  lifecycle system ready (n_r={n_r}, n_phi={n_phi}), rank {rank}/{world}")
+    t_loop0 = time.time()                               # ``stats`` (bench.py): the one-off set-up apart from the frame loop
 
     for frame in range(n_frames):
         t = frame * dt
@@ -348,6 +349,8 @@ def render_video(renderer: HipRenderer, width: int, height: int, n_frames: int, 
 
     frames_written, bytes_written = sink.drain()
     sink.close()
+    if stats is not None:
+        stats.update(setup_s=t_loop0 - total_t0, loop_s=time.time() - t_loop0, frames=rendered)
     streamed = False
     if stream is not None:
         try:

@@ -101,16 +101,18 @@ def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
 
 
 def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_differentials=False,
-                 skip_bloom=False, lens_flare=False, gather: str = "host", schedule: str = "auto", live=None):
+                 skip_bloom=False, lens_flare=False, gather: str = "host", schedule: str = "auto", live=None,
+                 time_march: bool = False):
     """Render one frame with the row-block renderers ``tiles`` (HipRenderer objects whose rows tile
     the image in order).  gather="host": returns the (H, W, 3) float32 frame, assembled from per-device pinned
-    buffers.  gather="peer": the tiles are gathered on tiles[0]'s device with hipMemcpyPeerAsync (xGMI) and stay
-    there -- returns None, read_gathered(tiles) fetches the frame.  gather="peer_u8": the same with the quantised
-    rows (a quarter of the bytes; read_gathered_u8).  gather="none": the rows stay in their tiles.
-    schedule: "pipelined" (halo pull under the V pass of the rows that need no halo, row chunks pushed while the next
-    chunk's V kernel runs, csrc/group.hip), "serial" (step after step; same bytes) or "auto" (default: pipelined where the
+    buffers.  gather="peer": every tile's V pass stores its f32 rows straight into the frame buffer on tiles[0]'s device
+    (peer memory over xGMI) -- returns None, read_gathered(tiles) fetches the frame.  gather="peer_u8": the same with the
+    quantised rows (a quarter of the bytes; read_gathered_u8).  gather="none": the rows stay in their tiles.
+    schedule: "pipelined" (the rows that need no halo go through the V pass first, under the neighbours' H passes,
+    csrc/group.hip), "serial" (one V launch behind the wait; same bytes) or "auto" (default: pipelined where the
     tiles sit on distinct devices, serial where they share one).  live: per-tile 0/1 -- only those tiles render, the
-    others keep the buffers of the last call in which they did (bench.py times one tile of eight that way)."""
+    others keep the buffers of the last call in which they did (bench.py times one tile of eight that way).
+    time_march: also record every tile's march-end event (counters()["march_ms"]; a ~5 us bubble in the tile's stream)."""
     if gather not in ("host", "peer", "peer_u8", "none"):
         raise ValueError(f"gather must be 'host', 'peer', 'peer_u8' or 'none', got {gather!r}")
     if schedule not in ("auto", "pipelined", "serial"):
@@ -124,6 +126,8 @@ def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_diff
         flags |= _lib.LENS_FLARE
     flags |= {"auto": 0, "serial": _lib.GROUP_SERIAL, "pipelined": _lib.GROUP_PIPELINED}[schedule]
     flags |= {"host": 0, "none": 0, "peer": _lib.GATHER_PEER, "peer_u8": _lib.GATHER_U8}[gather]
+    if time_march:
+        flags |= _lib.GROUP_TIME_MARCH
     live_arr = None
     if live is not None:
         if len(live) != len(tiles):
@@ -195,11 +199,12 @@ class TileLink:
         self._words = (C.c_uint64 * (world * _lib.TILE_SHM_WORDS)).from_buffer(self._shm.buf)
         _lib.check(self._lib.bhr_tile_connect(renderer._ctx, rank, world, arr, self._words))
 
-    def render(self, cam_pos, fov: float, frame: int = 0, skip_bloom: bool = False) -> None:
+    def render(self, cam_pos, fov: float, frame: int = 0, skip_bloom: bool = False, time_march: bool = False) -> None:
         """One frame: this rank's tile, pipelined; returns when every rank's rows have landed on rank 0's device."""
         r = self.renderer
         cam = r.camera_uniforms(cam_pos, fov, frame)
-        _lib.check(self._lib.bhr_tile_render(r._ctx, C.byref(cam), r._flags(False, skip_bloom) | self._gflag))
+        _lib.check(self._lib.bhr_tile_render(r._ctx, C.byref(cam), r._flags(False, skip_bloom) | self._gflag
+                                             | (_lib.GROUP_TIME_MARCH if time_march else 0)))
 
     def read_gathered(self) -> np.ndarray:
         return (read_gathered if self.gather == "peer" else read_gathered_u8)([self.renderer])

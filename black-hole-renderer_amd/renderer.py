@@ -470,6 +470,15 @@ class HipRenderer:
         _lib.check(self._lib.bhr_selftest(self._ctx, out))
         return {"bad_sqrt": out[0], "bad_div": out[1], "bad_div6": out[2], "checked": out[3]}
 
+    def hybrid_launch_order(self) -> np.ndarray:
+        """The partitioned launch order of the last math="hybrid" march: tile indices, the strict tiles first
+        (bhr_debug_read, which = 2).  Diagnostics."""
+        geom = (C.c_int32 * 10)()
+        _lib.check(self._lib.bhr_debug_read(self._ctx, 2, None, 0, geom))
+        out = np.empty(int(geom[0]), dtype=np.int32)
+        _lib.check(self._lib.bhr_debug_read(self._ctx, 2, out.ctypes.data, out.nbytes, None))
+        return out
+
     def hybrid_info(self) -> dict:
         """Tile split and band of the last math="hybrid" march (bhr_hybrid_info)."""
         t, b = (C.c_int32 * 2)(), (C.c_double * 2)()

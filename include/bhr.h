@@ -115,6 +115,9 @@ typedef struct {
 #define BHR_GROUP_PIPELINED 2048u  /* bhr_group_render: the pipelined schedule (halo pull under the V pass of the middle rows, row
                                       chunks pushed while the next chunk's V kernel runs).  Neither flag: pipelined where the
                                       tiles sit on distinct devices, serial where they share one */
+#define BHR_GROUP_TIME_MARCH 4096u /* bhr_group_render / bhr_tile_render: also record every tile's march-end event (bhr_counters.march_ms /
+                                      bloom_ms of the tiles; frame_ms is always available).  Off by default: the record is a ~5 us bubble
+                                      between the march and the H pass of every tile */
 #define BHR_GATHER_PEER      128u  /* bhr_group_render: gather the tiles into one (H, W, 3) buffer on ctxs[0]'s device with
                                       hipMemcpyPeerAsync (xGMI), one copy per tile on the tile's own stream */
 
@@ -254,6 +257,10 @@ BHR_API int32_t bhr_set_outputs(bhr_ctx *ctx, uint32_t mask);
  *   "hybrid_repair"   BHR_HYBRID_REPAIR   -1 guards + strict fix list by view (anti-aliased or tilted), 0 / 1 force
  *   "hybrid_band_lo" / "hybrid_band_hi" / "hybrid_band_default"   BHR_HYBRID_BAND="lo,hi"   strict band around b_c, in r_s
  *   "hybrid_streams"  BHR_HYBRID_STREAMS  2 the two lists of a hybrid march on two streams, 1 on one
+ *   "hybrid_swap"     BHR_HYBRID_SWAP     1 (default) the fast list of a two-stream hybrid march on the frame's own stream (the
+ *                                         post-pass follows it on one hardware queue), the strict list on the second; 0 swapped
+ *   "hybrid_classify" BHR_HYBRID_CLASSIFY 1 (default) a view change classifies the tiles and partitions the launch order on the
+ *                                         device (~0.05 ms whatever the size), 0 on the submitting thread (the same lists)
  *   "mip_lds"         BHR_MIP_LDS         1 anti-aliased fast frames stage the coarse mip levels in LDS
  *   "tile_order_rows" BHR_TILE_ORDER=row  1 row-major march launch order
  *   "group_threads"   BHR_GROUP_THREADS   -1 one submitting thread per tile where the tiles sit on distinct devices, 0 / 1 force
@@ -262,7 +269,9 @@ BHR_API int32_t bhr_set_outputs(bhr_ctx *ctx, uint32_t mask);
 BHR_API int32_t bhr_set_option(bhr_ctx *ctx, const char *name, double value);
 /* Diagnostics (tests): the split-f16 post-pass's packed intermediates of the last frame as raw bytes -- which = 0 the H pass's
  * input (csrc/bloom.hip: pa), 1 its output / the V pass's input (pb) -- and the layout's geometry: geom[10] = {NT, n_tx, WP, YB,
- * GP, g0, t_first, n_ty, pbr, GR}.  out == NULL or bytes == 0: geometry only.  Synchronises. */
+ * GP, g0, t_first, n_ty, pbr, GR}; which = 2 the launch order of the last math-hybrid march as int32 tile indices, strict tiles
+ * first (geom[0] = tiles in it; bhr_hybrid_info tells how many are strict).  out == NULL or bytes == 0: geometry only.
+ * Synchronises. */
 BHR_API int32_t bhr_debug_read(bhr_ctx *ctx, int32_t which, void *out, int64_t bytes, int32_t *geom);
 /* TaichiRenderer._apply_lens_flare(final, disk) (render.py:3925-4028) on the device, standalone:
  * FINAL <- clip(FINAL + flare(DISK), 0, 1) for a whole-frame context.  bhr_render / bhr_group_render

@@ -27,9 +27,9 @@ pa = pa.reshape(3, 2, YB, GP, 32, 8).astype(np.float64)
 v = (pa[:, 0] + pa[:, 1]) / 16384.0                       # [c][yb][g][yy][j]
 v = v[:, :, g0:g0 + W // 8].transpose(1, 3, 2, 4, 0).reshape(YB * 32, W, 3)[:H]
 print("pa vs input: max", np.abs(v - x).max())
-pb = pb.reshape(3, 2, GR, WP, 8).astype(np.float64)
-hb = (pb[:, 0] + pb[:, 1]) / 16384.0                      # [c][gr][x][j]
-hb = hb.transpose(1, 3, 2, 0).reshape(GR * 8, WP, 3)
+pb = pb.reshape(3, 2, WP // 32, GR, 32, 8).astype(np.float64)
+hb = (pb[:, 0] + pb[:, 1]) / 16384.0                      # [c][strip][gr][n][j]
+hb = hb.transpose(2, 4, 1, 3, 0).reshape(GR * 8, WP, 3)
 r0 = 0 - pbr
 hb = hb[r0:r0 + H, :W]
 # numpy H pass
@@ -46,5 +46,5 @@ dd = np.abs(hb - ref)
 print("pb vs numpy H pass: max", dd.max(), "count>1e-6", int((dd > 1e-6).sum()))
 ys, xs, cs = np.nonzero(dd > 1e-6)
 for y, xx_, c in list(zip(ys, xs, cs))[:12]:
-    h_, l_ = pb[c, 0, (y + r0) // 8, xx_, (y + r0) % 8], pb[c, 1, (y + r0) // 8, xx_, (y + r0) % 8]
+    h_, l_ = pb[c, 0, xx_ // 32, (y + r0) // 8, xx_ % 32, (y + r0) % 8], pb[c, 1, xx_ // 32, (y + r0) // 8, xx_ % 32, (y + r0) % 8]
     print(y, xx_, c, "got", hb[y, xx_, c], "ref", ref[y, xx_, c], "hi", h_, "lo", l_, "ref*16384", ref[y, xx_, c] * 16384)
