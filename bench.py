@@ -598,6 +598,11 @@ def main():
             except Exception:
                 traffic = None
         valu_tflops = MARCH_FLOP_PER_RAY_STEP * k_steps / (march_ms * 1e-3) / 1e12
+        try:
+            stream_map = renderer.stream_map()      # after the timed region: which of the context's streams share a hardware queue
+        except Exception as e:
+            stream_map = {"error": str(e)}
+        stream_cal = renderer.stream_calibration()
         out = {
             "metric": "Mray-steps/s", "value": total_steps / elapsed / 1e6, "unit": "Mray-steps/s",
             "fps": world * args.steps / elapsed,
@@ -614,6 +619,7 @@ def main():
                        "spin_up": f"{n_spin} un-timed frames ({args.spin_up_ms:g} ms) before the {args.warmup} warm-up steps",
 
                        "ray_steps_per_frame": int(steps_per_frame), "steps_per_ray": steps_per_frame / pixels},
+            "stream_map": stream_map, "stream_calibration": stream_cal,
             "kernel_ms": {"march": march_ms, "bloom_combine_flare" if flare else "bloom_and_combine": bloom_ms, "frames_timed": k_frames,
                           "march_vgprs": c["march_vgprs"],
                           "how": "HIP events on the launching stream, isolated launches (one frame slot)"

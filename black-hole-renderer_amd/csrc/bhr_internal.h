@@ -127,7 +127,8 @@ struct bhr_options {
     int32_t hybrid_repair;      // BHR_HYBRID_REPAIR: -1 by view (default), 0 / 1 guards + strict fix list off / on
     double hybrid_band[2];      // BHR_HYBRID_BAND="lo,hi": strict band around b_c in r_s (default 0.085, 0.36)
     int32_t hybrid_band_set;
-    int32_t hybrid_streams;     // BHR_HYBRID_STREAMS: 1 both lists of a hybrid march on one stream, 2 (default) on two
+    int32_t hybrid_streams;     // BHR_HYBRID_STREAMS: 1 both lists of a hybrid march on one stream, 2 on two, -1 (default) 1 where two frame slots overlap frames, else 2
+    int32_t calibrate_streams;  // BHR_CALIBRATE_STREAMS: 1 (default) a two-slot context picks slot 1's stream by timing candidates (api.hip)
     int32_t hybrid_swap;        // BHR_HYBRID_SWAP: 1 (default) the fast list on the frame's stream and the strict one on the second, 0 the other way round
     int32_t hybrid_classify;    // BHR_HYBRID_CLASSIFY: 1 (default) the tiles are classified and the launch order partitioned on the device, 0 on the host
     int32_t mip_lds;            // BHR_MIP_LDS=1: anti-aliased fast frames stage the coarse mip levels in LDS
@@ -185,6 +186,10 @@ struct bhr_ctx {
     hipStream_t scene_stream;           // scene updates, read-backs, group renders
     bhr_frame_slot slots[BHR_MAX_FRAME_SLOTS];
     int32_t n_slots, next_slot, active_slot;
+    int32_t two_slot_frames, streams_calibrated, calibrating;   // calibrate_slot_streams (api.hip)
+    int32_t calib_choice, calib_fps[8];
+    hipStream_t calib_idle[8];
+    int32_t n_calib_idle;
     hipEvent_t scene_ev;                // scene stream -> slot stream ordering, recorded at every bhr_render
     hipEvent_t ev[8];
     // per-frame timing ring: 3 events per bhr_render (march start, march end, frame end)
@@ -353,6 +358,7 @@ int32_t bhr_ensure_outputs(bhr_ctx *ctx, uint32_t need);
 void bhr_pipe_free(bhr_ctx *ctx);                                          // group.hip
 int32_t bhr_ensure_pinned(bhr_ctx *ctx, size_t bytes);                     // api.hip
 // fork: the aux stream waits for everything ctx->stream has been given so far; join: ctx->stream waits for the aux stream
+int32_t bhr_streams_share_queue(hipStream_t a, hipStream_t b, int32_t *share);   // api.o: probe (two one-lane kernels, <= 4 ms)
 int32_t bhr_aux_fork(bhr_ctx *ctx);
 int32_t bhr_aux_join(bhr_ctx *ctx);
 int32_t bhr_launch_flare_glow(bhr_ctx *ctx, bool whole_frame);       // flare.hip

@@ -447,7 +447,11 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
         const int32_t *d_base = base.active ? base.d_list : ctx->d_tile_order;
         if (!d_base) return bhr_fail(BHR_ERR_INVALID, "hybrid march: the base list has no device copy");
         if (!h->cls_stream) {
-            BHR_HIP(hipStreamCreateWithFlags(&h->cls_stream, hipStreamNonBlocking));
+            // highest priority: the host waits for these four kernels; and HIP keeps a pool of hardware queues per priority, so this
+            // stream does not move the frame streams' places in the normal-priority pool (api.hip: pad_streams)
+            int lo_p = 0, hi_p = 0;
+            BHR_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+            BHR_HIP(hipStreamCreateWithPriority(&h->cls_stream, hipStreamNonBlocking, hi_p));
             BHR_HIP(hipMalloc((void **)&h->d_flags, (size_t)n_tiles));
             BHR_HIP(hipMalloc((void **)&h->d_counts, (size_t)((n_tiles + PART_BLOCK - 1) / PART_BLOCK + 1) * sizeof(int32_t)));
             BHR_HIP(hipMalloc((void **)&h->d_total, 2 * sizeof(int32_t)));
@@ -561,7 +565,9 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     // Two launches.  On ONE stream the fast list waits for the last strict wave (the chip drains in between); on TWO the
     // fast tiles run on the context's low-priority second stream beside the strict ones and fill the slots they leave.
     // The bracket (start event, counter clear / end event) is an empty first / last part on the frame's own stream.
-    int streams = ctx->opt.hybrid_streams;           // 2; BHR_HYBRID_STREAMS=1: both lists on the frame's stream
+    // one stream where two frame slots keep frames in flight (the other frame's kernels fill this one's gaps, and every further
+    // stream is one more place in HIP's queue lottery: DESIGN 7), two where a frame runs alone (row blocks, one slot)
+    int streams = ctx->opt.hybrid_streams > 0 ? ctx->opt.hybrid_streams : (ctx->n_slots > 1 && ctx->cur_slot >= 0 ? 1 : 2);
     if (base.active) streams = 1;                    // a pipelined row block already runs its two halves on two streams
     if (s.n_strict == 0) streams = 1;                // nothing for a second stream to do (row blocks away from the hole's image)
     int32_t rc = BHR_OK;

@@ -470,6 +470,27 @@ class HipRenderer:
         _lib.check(self._lib.bhr_selftest(self._ctx, out))
         return {"bad_sqrt": out[0], "bad_div": out[1], "bad_div6": out[2], "checked": out[3]}
 
+    def stream_map(self) -> dict:
+        """Which of the context's streams share a hardware queue (bhr_debug_read, which = 3: a probe of two one-lane kernels
+        per pair).  Keys "a+b" over scene / slot0 / slot1 / aux0 / aux1; True = one queue.  Diagnostics."""
+        geom = (C.c_int32 * 10)()
+        _lib.check(self._lib.bhr_debug_read(self._ctx, 3, None, 0, geom))
+        names = ["scene", "slot0", "slot1", "aux0", "aux1"]
+        out, q = {}, 0
+        for i in range(5):
+            for j in range(i + 1, 5):
+                if geom[q] >= 0:
+                    out[f"{names[i]}+{names[j]}"] = bool(geom[q])
+                q += 1
+        return out
+
+    def stream_calibration(self) -> dict:
+        """What the context's choice of slot 1's stream was made from (bhr_debug_read, which = 4): the candidates' frame
+        rates and the one kept; "done" False until the ninth two-slot frame."""
+        geom = (C.c_int32 * 10)()
+        _lib.check(self._lib.bhr_debug_read(self._ctx, 4, None, 0, geom))
+        return {"done": bool(geom[0]), "kept": int(geom[1]), "candidates_fps": [int(geom[2 + c]) for c in range(6)]}
+
     def hybrid_launch_order(self) -> np.ndarray:
         """The partitioned launch order of the last math="hybrid" march: tile indices, the strict tiles first
         (bhr_debug_read, which = 2).  Diagnostics."""

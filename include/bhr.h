@@ -256,7 +256,10 @@ BHR_API int32_t bhr_set_outputs(bhr_ctx *ctx, uint32_t mask);
  *   "bloom_tiles"     BHR_BLOOM_TILES     0 output tiles per wave of the split post-pass by launch size, 1..8 force (A/B runs)
  *   "hybrid_repair"   BHR_HYBRID_REPAIR   -1 guards + strict fix list by view (anti-aliased or tilted), 0 / 1 force
  *   "hybrid_band_lo" / "hybrid_band_hi" / "hybrid_band_default"   BHR_HYBRID_BAND="lo,hi"   strict band around b_c, in r_s
- *   "hybrid_streams"  BHR_HYBRID_STREAMS  2 the two lists of a hybrid march on two streams, 1 on one
+ *   "hybrid_streams"  BHR_HYBRID_STREAMS  -1 (default) the two lists of a hybrid march on one stream where two frame slots overlap
+ *                                         frames and on two where a frame runs alone; 1 / 2 force
+ *   "calibrate_streams" BHR_CALIBRATE_STREAMS 1 (default) a context with two frame slots times six candidate streams for slot 1 on
+ *                                         its ninth frame and keeps the fastest (~0.15 s once; csrc/api.hip: calibrate_slot_streams)
  *   "hybrid_swap"     BHR_HYBRID_SWAP     1 (default) the fast list of a two-stream hybrid march on the frame's own stream (the
  *                                         post-pass follows it on one hardware queue), the strict list on the second; 0 swapped
  *   "hybrid_classify" BHR_HYBRID_CLASSIFY 1 (default) a view change classifies the tiles and partitions the launch order on the

@@ -85,29 +85,43 @@ def test_hybrid_video_frames(hip_lib):
 
 def test_hybrid_whole_fhd_frame_vs_strict(hip_lib):
     """The BASELINE fhd bench frame (procedural sky + lifecycle texture): hybrid vs strict on all 2 073 600 pixels of the
-    three layers and the frame -- RMSE <= 3e-5 per channel (measured 1.3e-5 / 1.7e-5 / 2.3e-6), no pixel of the frame
-    beyond 1e-3, ray-step totals within 2e-4 (measured 1.3e-7); strict tiles are a small share of the frame."""
+    three layers and the frame -- RMSE <= 3e-5 per channel (measured 1.0e-5 / 1.2e-5 / 1.5e-5), ray-step totals within
+    2e-4 (measured 1.3e-7); strict tiles are a small share of the frame.
+
+    Single pixels: the fast arithmetic's rounding can move a ray across one of the ALGORITHM'S OWN switches -- a disk
+    crossing in the terminating step, a truncated mip level -- and such a pixel then differs by a visible share of a disk
+    colour, far from the strict band (round 4: two mirror-image pixels at b = b_c + 1.0, 9e-3 and 4e-3; round 3's
+    re-association of the same step had none).  Those are what the guard / fix-list launches exist for (hybrid_repair,
+    default on for anti-aliased and tilted views, off here for its 17 % of the fhd frame rate): without them at most 4
+    pixels beyond 1e-3 and none beyond 2e-2; with them none beyond 1e-3."""
     import bench
     from bhr_amd import _lib, workloads
     wl = bench.WORKLOADS["fhd"]
     r, _, _, _ = workloads.make_scene(wl, frame_slots=1)
     lay = {}
-    for math in ("strict", "hybrid"):
+    for math, repair in (("strict", -1), ("hybrid", -1), ("hybrid", 1)):
+        r.set_option("hybrid_repair", repair)
         r.render_async(wl["cam_pos"], wl["fov"], math=math)
-        lay[math] = dict(final=r.read_layer(_lib.LAYER_FINAL), bg=r.read_layer(_lib.LAYER_BG), disk=r.read_layer(_lib.LAYER_DISK),
-                         steps=r.counters()["ray_steps"])
-    info = r.hybrid_info()
+        lay[(math, repair)] = dict(final=r.read_layer(_lib.LAYER_FINAL), bg=r.read_layer(_lib.LAYER_BG), disk=r.read_layer(_lib.LAYER_DISK),
+                                   steps=r.counters()["ray_steps"])
+        if math == "hybrid":
+            info = r.hybrid_info()
+            assert (info["repaired_pixels"] > 0) == (repair == 1), info
     r.close()
+    ref = lay[("strict", -1)]
     assert info["strict_tiles"] / info["tiles"] <= 0.12, info
-    assert abs(lay["hybrid"]["steps"] - lay["strict"]["steps"]) <= 2e-4 * lay["strict"]["steps"]
-    for k in ("final", "bg", "disk"):
-        e = _rmse_c(lay["hybrid"][k], lay["strict"][k])
-        assert (e <= MARGIN).all(), (k, e)
-    d = np.abs(lay["hybrid"]["final"] - lay["strict"]["final"]).max(axis=2)
-    print(f"\n[hybrid fhd] pixels beyond 1e-3: {int((d > 1e-3).sum())}, max {d.max():.3g}, per-channel RMSE {_rmse_c(lay['hybrid']['final'], lay['strict']['final'])}")
-    # single pixels next to the strict band carry the fast arithmetic's rounding amplified by b / |b - b_c|: which ones cross
-    # 1e-3 changes with every re-association of the step (round 3: none, max 6.9e-4; round 4's one-transcendental step: 2)
-    assert (d > 1e-3).sum() <= 4 and d.max() <= 3e-3, (int((d > 1e-3).sum()), float(d.max()))
+    for repair in (-1, 1):
+        got = lay[("hybrid", repair)]
+        assert abs(got["steps"] - ref["steps"]) <= 2e-4 * ref["steps"]
+        for k in ("final", "bg", "disk"):
+            e = _rmse_c(got[k], ref[k])
+            assert (e <= MARGIN).all(), (repair, k, e)
+        d = np.abs(got["final"] - ref["final"]).max(axis=2)
+        print(f"\n[hybrid fhd, repair {repair}] pixels beyond 1e-3: {int((d > 1e-3).sum())}, max {d.max():.3g}, per-channel RMSE {_rmse_c(got['final'], ref['final'])}")
+        if repair == 1:
+            assert (d > 1e-3).sum() == 0, (int((d > 1e-3).sum()), float(d.max()))
+        else:
+            assert (d > 1e-3).sum() <= 4 and d.max() <= 2e-2, (int((d > 1e-3).sum()), float(d.max()))
 
 
 def test_hybrid_strict_tiles_are_bit_identical_to_strict(hip_lib):
