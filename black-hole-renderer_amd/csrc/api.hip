@@ -793,6 +793,8 @@ int32_t render_on_slot(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags, int 
 static int32_t calibrate_slot_streams(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     constexpr int NC = 6, FRAMES = 24;
     ctx->calibrating = 1;
+    const auto head0 = ctx->ring_head;
+    const int slot0 = ctx->next_slot;
     hipStream_t cand[NC] = {};
     double best_ms[NC];
     int32_t rc = alloc_slot(ctx, 0);
@@ -857,10 +859,14 @@ static int32_t calibrate_slot_streams(bhr_ctx *ctx, const bhr_camera *cam, uint3
         if (c != best && cand[c]) ctx->calib_idle[ctx->n_calib_idle++] = cand[c];
     ctx->calib_choice = best;
     for (int c = 0; c < 8; ++c) ctx->calib_fps[c] = c < n_cand && best_ms[c] < 1e29 ? (int32_t)(FRAMES * 1e3 / best_ms[c]) : 0;
-    // the timing ring starts over: the caller's frames are counted from here
-    (void)hipMemsetAsync(ctx->d_steps_ring, 0, sizeof(unsigned long long) * BHR_TIMING_RING * BHR_STEP_CELL, ctx->scene_stream);
+    // the timing ring goes on where the caller's frames had brought it: the turns above ran through it (same view, same
+    // ray-step counts; their event times stand in for the few frames before them), the next frames' counter cells are cleared
+    // as the V pass of their predecessors would have left them
+    for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q)
+        (void)hipMemsetAsync(ctx->d_steps_ring + (size_t)((head0 + q) % BHR_TIMING_RING) * BHR_STEP_CELL, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->scene_stream);
     (void)hipStreamSynchronize(ctx->scene_stream);
-    ctx->ring_head = 0;
+    ctx->ring_head = head0;
+    ctx->next_slot = slot0;
     ctx->calibrating = 0;
     ctx->streams_calibrated = 1;
     return rc;
