@@ -992,7 +992,6 @@ int32_t bhr_set_option(bhr_ctx *ctx, const char *name, double value) {
     const int v = (int)value;
     bhr_options &o = ctx->opt;
     if (n == "bloom_split") o.bloom_split = v < 0 ? -1 : (v ? 1 : 0);
-    else if (n == "bloom_dbg") o.bloom_dbg = v;
     else if (n == "bloom_tiles") o.bloom_tiles = v < 0 || v > 8 ? 0 : v;
     else if (n == "hybrid_repair") o.hybrid_repair = v < 0 ? -1 : (v ? 1 : 0);
     else if (n == "hybrid_band_lo") { if (!o.hybrid_band_set) o.hybrid_band[1] = 0.36; o.hybrid_band[0] = value; o.hybrid_band_set = 1; }

@@ -122,7 +122,6 @@ struct bhr_march_part {
 struct bhr_options {
     int32_t frame_slots;        // BHR_FRAME_SLOTS: frames in flight per context (1 or 2, default 2)
     int32_t bloom_split;        // BHR_BLOOM_SPLIT: -1 by arithmetic (default), 0 exact f32 kernels always, 1 split-f16 always
-    int32_t bloom_dbg;          // experiments only
     int32_t bloom_tiles;        // BHR_BLOOM_TILES: output tiles per wave of the split-f16 post-pass (1..8; 0 = by launch size), A/B runs
     int32_t hybrid_repair;      // BHR_HYBRID_REPAIR: -1 by view (default), 0 / 1 guards + strict fix list off / on
     double hybrid_band[2];      // BHR_HYBRID_BAND="lo,hi": strict band around b_c in r_s (default 0.085, 0.36)

@@ -352,7 +352,6 @@ struct HSplitArgs {
     int32_t YB, GP, GR, pbr;
     int32_t NT, table_bytes, n_tx;
     int32_t seg, n_seg;        // output tiles per wave (<= T), segments per row of tiles
-    int32_t dbg;
     int32_t n_mirror;
     Mirror mirror[MAX_MIRRORS];
 };
@@ -368,19 +367,17 @@ struct VSplitArgs {
     int32_t NT, table_bytes, R;
     int32_t seg_t0, seg_t1;    // tiles' of this launch
     int32_t seg, n_seg;        // output tiles per wave (<= T), segments per strip
-    int32_t dbg;
     int32_t r_begin, r_end;    // local rows it stores
 };
 
 // the context's table (<= 60 KB) into LDS: every load of a thread issued before the first is waited for -- written as a
 // loop with a run-time trip count hipcc waits for each 16-byte load before it issues the next one (8-10 trips to L2 in a
 // row at the head of every workgroup: 10 us of the first version's 26 us per wave)
-__device__ __forceinline__ void stage_table(unsigned char *lds, const unsigned short *__restrict__ w16, int bytes, bool g_dbg_old_staging = false) {
+__device__ __forceinline__ void stage_table(unsigned char *lds, const unsigned short *__restrict__ w16, int bytes) {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(w16);
     u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
     constexpr int TRIPS = (48 * 1280 / 16 + SPLIT_THREADS - 1) / SPLIT_THREADS;      // the largest table: NT = 12
     const int n16 = bytes / 16;
-    if (g_dbg_old_staging) { for (int k = threadIdx.x; k < n16; k += SPLIT_THREADS) dst[k] = src[k]; return; }
     u32x4 tmp[TRIPS];
 #pragma unroll
     for (int i = 0; i < TRIPS; ++i) {
@@ -458,7 +455,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ch = wave % 3, unit = blockIdx.x * SPLIT_SUBS + wave / 3;
     if (unit >= a.n_seg * a.YB) {                    // no work: only the workgroup's table staging
-        stage_table(lds_b, a.w16, a.table_bytes, (a.dbg & 8) != 0);
+        stage_table(lds_b, a.w16, a.table_bytes);
         __syncthreads();
         return;
     }
@@ -500,21 +497,14 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     u32x4 d[SPLIT_DEPTH][2];
 #pragma unroll
     for (int j = 0; j < SPLIT_DEPTH; ++j) load(c0 + j, d[j]);
-    stage_table(lds_b, a.w16, a.table_bytes, (a.dbg & 8) != 0);
+    stage_table(lds_b, a.w16, a.table_bytes);
     __syncthreads();
-    for (int cp = c0; cp <= ((a.dbg & 1) ? c0 : c1); cp += SPLIT_DEPTH) {
+    for (int cp = c0; cp <= c1; cp += SPLIT_DEPTH) {
 #pragma unroll
         for (int j = 0; j < SPLIT_DEPTH; ++j) {
             if (cp + j <= c1) chunk(cp + j, d[j]);
             load(cp + j + SPLIT_DEPTH, d[j]);
         }
-    }
-    if (a.dbg & 2) {
-        float t = 0;
-#pragma unroll
-        for (int i = 0; i < T; ++i) t += acc[i][0] + acc[i][7] + acc[i][15];
-        if (t == 123.456f) *(volatile float *)a.w16 = t;
-        return;
     }
 
     // D: column = lane & 31 -> output pixel, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> row of the block: a lane's four
@@ -644,21 +634,14 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     u32x4 d[SPLIT_DEPTH][2];
 #pragma unroll
     for (int j = 0; j < SPLIT_DEPTH; ++j) load(c0 + j, d[j]);
-    stage_table(lds_b, a.w16, a.table_bytes, (a.dbg & 8) != 0);
+    stage_table(lds_b, a.w16, a.table_bytes);
     __syncthreads();
-    for (int cp = c0; cp <= ((a.dbg & 1) ? c0 : c1); cp += SPLIT_DEPTH) {
+    for (int cp = c0; cp <= c1; cp += SPLIT_DEPTH) {
 #pragma unroll
         for (int j = 0; j < SPLIT_DEPTH; ++j) {
             if (cp + j <= c1) chunk(cp + j, d[j]);
             load(cp + j + SPLIT_DEPTH, d[j]);
         }
-    }
-    if (a.dbg & 2) {
-        float t = 0;
-#pragma unroll
-        for (int i = 0; i < T; ++i) t += acc[i][0] + acc[i][7] + acc[i][15];
-        if (t == 123.456f) *(volatile float *)a.w16 = t;
-        return;
     }
 
     const float *__restrict__ winv = a.wsum_v + (size_t)(3 + ch) * a.H;    // 2^-24 / (in-bounds weight sum) of every image row
@@ -672,7 +655,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     // right edge keep the per-channel path.)
     // uniform over the workgroup: both of its units are whole strips of the SAME segment (the tile loop below is shared)
     const int u0 = blockIdx.x * SPLIT_SUBS, u1 = u0 + SPLIT_SUBS - 1;
-    const bool coop = (a.W & 3) == 0 && u1 < a.n_seg * n_strips && u0 / n_strips == u1 / n_strips && (u1 % n_strips + 1) * 32 <= a.W && !(a.dbg & 4);
+    const bool coop = (a.W & 3) == 0 && u1 < a.n_seg * n_strips && u0 / n_strips == u1 / n_strips && (u1 % n_strips + 1) * 32 <= a.W;
     float *tile = reinterpret_cast<float *>(lds_b + a.table_bytes) + sub * (32 * 96);
 #pragma unroll
     for (int i = 0; i < T; ++i) {
@@ -880,7 +863,6 @@ int32_t bhr_launch_bloom_h(bhr_ctx *ctx) {
             ++a.n_mirror;
         }
         if (ctx->n_mirrors > MAX_MIRRORS) return bhr_fail(BHR_ERR_INVALID, "bloom H: %d mirror planes (at most %d)", ctx->n_mirrors, MAX_MIRRORS);
-        a.dbg = ctx->opt.bloom_dbg & 15;
         const SplitPlan pl = plan_segments(g.n_tx, g.YB, g.NT, ctx->opt.bloom_tiles);
         a.seg = pl.seg;
         a.n_seg = pl.n_seg;
@@ -937,7 +919,6 @@ int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, in
         a.seg_t1 = (ctx->cfg.row0 + r1 - 1) / 32 - g.t_first + 1;
         a.r_begin = r0; a.r_end = r1;
         const int nt = a.seg_t1 - a.seg_t0;
-        a.dbg = (ctx->opt.bloom_dbg >> 4) & 15;
         const SplitPlan pl = plan_segments(nt, g.n_tx, g.NT, ctx->opt.bloom_tiles);
         a.seg = pl.seg;
         a.n_seg = pl.n_seg;

@@ -1433,7 +1433,11 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     a.wave_stamps = nullptr;
     // diagnostic (builds with -DBHR_WAVE_STAMPS_BUILD=1 only: the stamps cost the plain kernel three spilled registers):
     // BHR_WAVE_STAMPS=<file> dumps per-wave start / end times of THIS launch (tools/wave_timeline.py)
-    const char *stamp_path = BHR_WAVE_STAMPS_BUILD ? getenv("BHR_WAVE_STAMPS") : nullptr;
+#if BHR_WAVE_STAMPS_BUILD
+    const char *stamp_path = getenv("BHR_WAVE_STAMPS");
+#else
+    const char *stamp_path = nullptr;                          // the shipped library reads no environment on the render path
+#endif
     unsigned long long *d_stamps = nullptr;
     if (stamp_path && stamp_path[0]) {
         BHR_HIP(hipMalloc((void **)&d_stamps, (size_t)a.n_tiles * 4 * sizeof(unsigned long long)));

@@ -16,7 +16,6 @@ def main():
     only_split = [int(a.split("=")[1]) for a in args if a.startswith("split=")]
     only_out = [a.split("=")[1] for a in args if a.startswith("out=")]
     tiles = [int(a.split("=")[1]) for a in args if a.startswith("tiles=")] or [0]
-    dbgs = [int(a.split("=")[1]) for a in args if a.startswith("dbg=")] or [0]
     which = [a for a in args if "=" not in a] or ["fhd", "4k", "8k_tile", "8k"]
     sky, tex = scenes.analytic_skybox(128, 256), scenes.noisy_disk(256, 1024)
     out = {}
@@ -25,8 +24,7 @@ def main():
         for split in (only_split or (1, 0)):
           for outputs in (only_out or ("u8", "f32", "f32+blur+u8")):
            for nt in (tiles if split else [0]):
-            for dbg in dbgs:
-                r = HipRenderer(W, H, sky, tex, math="fast", frame_slots=1, rows=rows, outputs=outputs, options={"bloom_split": split, "bloom_tiles": nt, "bloom_dbg": dbg},
+                r = HipRenderer(W, H, sky, tex, math="fast", frame_slots=1, rows=rows, outputs=outputs, options={"bloom_split": split, "bloom_tiles": nt},
                                 **dict(KW, step_size=0.3 if W > 4000 else 0.1))
                 for _ in range(3):
                     r.render_async([6, 0, 0.5], 90)
@@ -37,7 +35,7 @@ def main():
                 c = r.counters()
                 ms = c["bloom_ms_sum"] / c["frames_timed"]
                 px = W * ((rows[1] - rows[0]) if rows else H)
-                key = f"{name}/{'split' if split else 'exact'}/{outputs}/t{nt}/d{dbg}"
+                key = f"{name}/{'split' if split else 'exact'}/{outputs}/t{nt}"
                 out[key] = {"post_ms": round(ms, 4), "march_ms": round(c["march_ms_sum"] / c["frames_timed"], 4),
                             "GB_per_s_algorithmic_24B_per_px": round(px * 24 / ms / 1e6, 1)}
                 print(key, out[key], flush=True)
