@@ -594,10 +594,11 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ch = wave % 3, sub = wave / 3, n_strips = a.WP / 32;
-    int unit = blockIdx.x * SPLIT_SUBS + sub;
+    const int wg = blockIdx.x;
+    int unit = wg * SPLIT_SUBS + sub;                 // strip-major: a strip's segments are neighbours (they share 2 NT - 2 chunks)
     const bool live = unit < a.n_seg * n_strips;     // a unit past the end walks unit 0 and stores nothing: every wave reaches the barriers below
     if (!live) unit = 0;
-    const int yseg = unit / n_strips, strip = unit - yseg * n_strips;
+    const int strip = unit / a.n_seg, yseg = unit - strip * a.n_seg;
     const int n = lane & 31, h = lane >> 5, NT = a.NT;
     const int x = strip * 32 + n;
     const int tb = a.seg_t0 + yseg * a.seg, te = min(tb + a.seg, a.seg_t1);
@@ -653,16 +654,27 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     // 768 float4s: 16-byte loads of bg and disk, 16-byte stores of the f32 frame and the blur, 4-byte stores of the u8
     // rows, every instruction on whole 384-byte row segments.  (Widths that are not multiples of 4 and the partial strip at the
     // right edge keep the per-channel path.)
-    // uniform over the workgroup: both of its units are whole strips of the SAME segment (the tile loop below is shared)
-    const int u0 = blockIdx.x * SPLIT_SUBS, u1 = u0 + SPLIT_SUBS - 1;
-    const bool coop = (a.W & 3) == 0 && u1 < a.n_seg * n_strips && u0 / n_strips == u1 / n_strips && (u1 % n_strips + 1) * 32 <= a.W;
+    // The workgroup's units may be segments of different lengths (the last one of a strip): the barriers below are passed by
+    // all six waves `n_it` times, the longest of them; a unit works in the rounds it has a tile for.
+    const bool coop = (a.W & 3) == 0;                                   // uniform over the launch
+    const bool whole = (strip + 1) * 32 <= a.W;                         // this unit's strip is 32 full columns
+    int n_it = 0;
+#pragma unroll
+    for (int q = 0; q < SPLIT_SUBS; ++q) {
+        const int u = wg * SPLIT_SUBS + q;
+        if (u < a.n_seg * n_strips) {
+            const int b0 = a.seg_t0 + (u % a.n_seg) * a.seg;
+            n_it = max(n_it, min(b0 + a.seg, a.seg_t1) - b0);
+        }
+    }
     float *tile = reinterpret_cast<float *>(lds_b + a.table_bytes) + sub * (32 * 96);
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-        if (tb + i >= te) continue;                                     // coop: uniform over the workgroup (one segment)
+        if (i >= n_it) break;
+        const bool on = live && tb + i < te;
         const int yg0 = 32 * (a.t_first + tb + i);
-        if (!coop) {
-            if (!live || x >= a.W) continue;
+        if (!coop || !whole) {
+            if (on && x < a.W) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int yg = yg0 + (r & 3) + 8 * (r >> 2) + 4 * h, yl = yg - a.row0;
@@ -676,12 +688,15 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
                     if (a.out.u8) a.out.u8[at] = (uint8_t)(int)(f * 255.0f);
                 }
             }
-            continue;
+            }
+            if (!coop) continue;
         }
+        const bool mine = on && whole;
         // rows whose whole +-R window lies inside the image share one weight sum (the table kernel adds the same weights in
         // the same order for each): 16 loads per tile -- and the s_waitcnt vmcnt(0) in front of their use, which also waits
         // for the previous tile's stores -- only for the tiles within R of the image's top and bottom
-        if (yg0 >= a.R && yg0 + 31 + a.R < a.H) {
+        if (!mine) {
+        } else if (yg0 >= a.R && yg0 + 31 + a.R < a.H) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -697,7 +712,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
         // this lane's four float4s of the frame's bg + disk: on their way before the barrier, not behind it (every wave of the
         // workgroup used to stop at the barrier and THEN start a trip to memory, once per tile)
         float4 sv[4];
-        const bool combine = a.out.final_f32 || a.out.u8;
+        const bool combine = mine && (a.out.final_f32 || a.out.u8);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = it * 192 + ch * 64 + lane;                  // float4 index into the tile: 24 per row
@@ -711,7 +726,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
             const int idx = it * 192 + ch * 64 + lane;
             const int row = idx / 24, q4 = idx - row * 24;
             const int yl = yg0 + row - a.row0;
-            if (yl < a.r_begin || yl >= a.r_end) continue;
+            if (!mine || yl < a.r_begin || yl >= a.r_end) continue;
             const float4 b = *reinterpret_cast<const float4 *>(tile + row * 96 + 4 * q4);
             const size_t at = ((size_t)yl * a.W + strip * 32) * 3 + 4 * q4;
             if (a.out.blur) *reinterpret_cast<float4 *>(a.out.blur + at) = b;
