@@ -35,69 +35,88 @@ __constant__ int c_perm256[256] = {
 };
 
 // perm_field = _perm + _perm (512 entries, render.py:2287-2288) staged in LDS.
-// perm[0..511] = the table, perm[512..1023] = the table modulo 12: the gradient index h = hash % 12 of the four corner
-// hashes is read directly instead of being computed (four integer divisions by a constant per evaluation).
+// perm[0..511] = the table, perm[512..1023] = 16 x (the table modulo 12): the byte offset of gradient h = hash % 12 in the
+// gradient table behind it (perm + 1024: twelve float4 rows), read directly instead of being computed (four integer
+// divisions by a constant per evaluation).
 typedef uint8_t perm_t;   // byte tables: 1 KB in all, lanes that hit the same LDS word are served by one broadcast
+constexpr int PERM_LDS_BYTES = 1024 + 12 * 16;
 __device__ __forceinline__ void load_perm(perm_t *perm) {
     for (int k = threadIdx.x; k < 512; k += blockDim.x) {
         const int v = c_perm256[k & 255];
         perm[k] = (perm_t)v;
-        perm[512 + k] = (perm_t)(v % 12);
+        perm[512 + k] = (perm_t)((v % 12) * 16);
+    }
+    // _grad3_dot (render.py:2642-2660) as a table: h = hash % 12 (its "h == 12 or 14" arm is dead), u = h < 8 ? x : y,
+    // v = h < 4 ? y : z, dot = (h & 1 ? -u : u) + (h & 2 ? -v : v) = gx x + gy y + gz z with one component zero.  Rows are 16
+    // bytes in 4 banks each, 12 rows in banks 0..47: a wave's 64 reads never conflict.
+    if (threadIdx.x < 12) {
+        const int h = threadIdx.x;
+        float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float su = (h & 1) == 0 ? 1.0f : -1.0f, sv = (h & 2) == 0 ? 1.0f : -1.0f;
+        g[h < 8 ? 0 : 1] += su;
+        g[h < 4 ? 1 : 2] += sv;
+        float *row = reinterpret_cast<float *>(perm + 1024) + 4 * h;
+        row[0] = g[0]; row[1] = g[1]; row[2] = g[2]; row[3] = 0.0f;
     }
     __syncthreads();
 }
 
-// _grad3_dot (render.py:2642-2660): h = hash % 12 so the "h == 12 or 14" arm is dead.
-__device__ __forceinline__ float grad3_dot(int h, float x, float y, float z) {   // h = hash % 12 (load_perm)
-    float u = h < 8 ? x : y;
-    float v = h < 4 ? y : z;
-    float r1 = (h & 1) == 0 ? u : -u;
-    float r2 = (h & 2) == 0 ? v : -v;
-    return r1 + r2;
+// the reference's r1 + r2 (one rounding of the sum of two of +-x, +-y, +-z): the products with +-1 and 0 are exact, each fma
+// rounds once, and the term with the zero coefficient adds +-0 -- the same bits from three instructions instead of eleven
+__device__ __forceinline__ float grad3_dot(const perm_t *perm, int h16, float x, float y, float z) {   // h16 = 16 (hash % 12) (load_perm)
+    const float4 g = *reinterpret_cast<const float4 *>(perm + 1024 + h16);
+    return __builtin_fmaf(g.x, x, __builtin_fmaf(g.y, y, g.z * z));
 }
 
-// _simplex_noise_3d (render.py:2662-2750)
+// _simplex_noise_3d (render.py:2662-2750), written without branches: 42 evaluations per texel of the background
+// generator, and as the reference's nested ifs (simplex ordering, `if t >= 0` around every corner) hipcc emitted 7 exec-mask
+// branches and ~24 v_mov per evaluation (212 VALU instructions each; the kernel ran at 67 % of its issue bound).
+//   ordering   A = x0 >= y0, B = y0 >= z0, C = x0 >= z0 select the reference's six cases (the truth table of its if tree);
+//   corners    t < 0 contributes nothing there; here t = max(t, 0) contributes t^4 dot = +-0, and n + (+-0) = n bit for bit
+//              (n starts at +0 and a sum never becomes -0);
+//   floor      (float)i of i = (int)floorf(v) IS floorf(v), and (float)(i + j + k) the exact sum of the three floors.
+// Same f32 operations in the same order otherwise (-ffp-contract=off for this file).
 __device__ __forceinline__ float simplex3(const perm_t *perm, float x, float y, float z) {
     const float F3 = 1.0f / 3.0f;
     const float G3 = 1.0f / 6.0f;
-    float s = (x + y + z) * F3;
-    int i = (int)floorf(x + s);
-    int j = (int)floorf(y + s);
-    int k = (int)floorf(z + s);
-    float t = (float)(i + j + k) * G3;
-    float x0 = x - ((float)i - t);
-    float y0 = y - ((float)j - t);
-    float z0 = z - ((float)k - t);
-    int i1, j1, k1, i2, j2, k2;
-    if (x0 >= y0) {
-        if (y0 >= z0)      { i1 = 1; j1 = 0; k1 = 0; i2 = 1; j2 = 1; k2 = 0; }
-        else if (x0 >= z0) { i1 = 1; j1 = 0; k1 = 0; i2 = 1; j2 = 0; k2 = 1; }
-        else               { i1 = 0; j1 = 0; k1 = 1; i2 = 1; j2 = 0; k2 = 1; }
-    } else {
-        if (y0 < z0)       { i1 = 0; j1 = 0; k1 = 1; i2 = 0; j2 = 1; k2 = 1; }
-        else if (x0 < z0)  { i1 = 0; j1 = 1; k1 = 0; i2 = 0; j2 = 1; k2 = 1; }
-        else               { i1 = 0; j1 = 1; k1 = 0; i2 = 1; j2 = 1; k2 = 0; }
-    }
-    float x1 = x0 - (float)i1 + G3, y1 = y0 - (float)j1 + G3, z1 = z0 - (float)k1 + G3;
-    float x2 = x0 - (float)i2 + 2.0f * G3, y2 = y0 - (float)j2 + 2.0f * G3, z2 = z0 - (float)k2 + 2.0f * G3;
-    float x3 = x0 - 1.0f + 3.0f * G3, y3 = y0 - 1.0f + 3.0f * G3, z3 = z0 - 1.0f + 3.0f * G3;
-    int ii = i & 255, jj = j & 255, kk = k & 255;
-    int pk0 = perm[kk], pk1 = perm[kk + 1];
+    // an evaluation starts HERE: without branches nothing stops the optimiser from starting all 42 evaluations of a texel
+    // at once (331 VGPRs, or hundreds of spills under an occupancy bound; the branchy version needed 62)
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+    const float s = (x + y + z) * F3;
+    const float fi = floorf(x + s), fj = floorf(y + s), fk = floorf(z + s);
+    const int i = (int)fi, j = (int)fj, k = (int)fk;
+    const float t = ((fi + fj) + fk) * G3;
+    const float x0 = x - (fi - t), y0 = y - (fj - t), z0 = z - (fk - t);
+    const bool A = x0 >= y0, B = y0 >= z0, C = x0 >= z0;
+    const bool i1 = A && (B || C), j1 = !A && B, k1 = !B && (!A || !C);
+    const bool i2 = A || (B && C), j2 = !A || B, k2 = (A && !B) || (!A && !(B && C));
+    const float x1 = x0 - (i1 ? 1.0f : 0.0f) + G3, y1 = y0 - (j1 ? 1.0f : 0.0f) + G3, z1 = z0 - (k1 ? 1.0f : 0.0f) + G3;
+    const float x2 = x0 - (i2 ? 1.0f : 0.0f) + 2.0f * G3, y2 = y0 - (j2 ? 1.0f : 0.0f) + 2.0f * G3, z2 = z0 - (k2 ? 1.0f : 0.0f) + 2.0f * G3;
+    const float x3 = x0 - 1.0f + 3.0f * G3, y3 = y0 - 1.0f + 3.0f * G3, z3 = z0 - 1.0f + 3.0f * G3;
+    const int ii = i & 255, jj = j & 255, kk = k & 255;
+    const int pk0 = perm[kk], pk1 = perm[kk + 1];
     const perm_t *perm12 = perm + 512;
-    int gi0 = perm12[ii + perm[jj + pk0]];
-    int gi1 = perm12[ii + i1 + perm[jj + j1 + (k1 ? pk1 : pk0)]];
-    int gi2 = perm12[ii + i2 + perm[jj + j2 + (k2 ? pk1 : pk0)]];
-    int gi3 = perm12[ii + 1 + perm[jj + 1 + pk1]];
+    const int gi0 = perm12[ii + perm[jj + pk0]];
+    const int gi1 = perm12[ii + (int)i1 + perm[jj + (int)j1 + (k1 ? pk1 : pk0)]];
+    const int gi2 = perm12[ii + (int)i2 + perm[jj + (int)j2 + (k2 ? pk1 : pk0)]];
+    const int gi3 = perm12[ii + 1 + perm[jj + 1 + pk1]];
     float n = 0.0f;
-    float t0 = 0.6f - x0 * x0 - y0 * y0 - z0 * z0;
-    if (t0 >= 0.0f) { t0 = t0 * t0; n += t0 * t0 * grad3_dot(gi0, x0, y0, z0); }
-    float t1 = 0.6f - x1 * x1 - y1 * y1 - z1 * z1;
-    if (t1 >= 0.0f) { t1 = t1 * t1; n += t1 * t1 * grad3_dot(gi1, x1, y1, z1); }
-    float t2 = 0.6f - x2 * x2 - y2 * y2 - z2 * z2;
-    if (t2 >= 0.0f) { t2 = t2 * t2; n += t2 * t2 * grad3_dot(gi2, x2, y2, z2); }
-    float t3 = 0.6f - x3 * x3 - y3 * y3 - z3 * z3;
-    if (t3 >= 0.0f) { t3 = t3 * t3; n += t3 * t3 * grad3_dot(gi3, x3, y3, z3); }
-    return 32.0f * n;
+    float t0 = fmaxf(0.6f - x0 * x0 - y0 * y0 - z0 * z0, 0.0f);
+    t0 = t0 * t0;
+    n += t0 * t0 * grad3_dot(perm, gi0, x0, y0, z0);
+    float t1 = fmaxf(0.6f - x1 * x1 - y1 * y1 - z1 * z1, 0.0f);
+    t1 = t1 * t1;
+    n += t1 * t1 * grad3_dot(perm, gi1, x1, y1, z1);
+    float t2 = fmaxf(0.6f - x2 * x2 - y2 * y2 - z2 * z2, 0.0f);
+    t2 = t2 * t2;
+    n += t2 * t2 * grad3_dot(perm, gi2, x2, y2, z2);
+    float t3 = fmaxf(0.6f - x3 * x3 - y3 * y3 - z3 * z3, 0.0f);
+    t3 = t3 * t3;
+    n += t3 * t3 * grad3_dot(perm, gi3, x3, y3, z3);
+    // ... and ends here: the two volatile statements keep their order, the arithmetic between them hangs on both
+    float out = 32.0f * n;
+    asm volatile("" : "+v"(out));
+    return out;
 }
 
 // _fbm_3d (render.py:2752-2785)
@@ -129,7 +148,7 @@ __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f),
 // _generate_background_kernel (render.py:3332-3451); writes comp[0,1,2,3,4,11,12].
 __global__ __launch_bounds__(256) void background_kernel(float *__restrict__ comp, int n_r, int n_phi, int az_freq,
                                                          float az_shear, float r_inner, float r_outer, float t) {
-    __shared__ perm_t perm[1024];
+    __shared__ __attribute__((aligned(16))) perm_t perm[PERM_LDS_BYTES];
     __shared__ float row_pow[2];
     const int ri = blockIdx.y;
     // The libm calls are evaluated in binary64 and rounded once -- what the reference's statements evaluate to under
@@ -277,7 +296,7 @@ __global__ __launch_bounds__(256) void mip_down_kernel(const float4 *__restrict_
 __global__ __launch_bounds__(256) void noise_eval_kernel(const float *__restrict__ coords, float *__restrict__ out,
                                                          long long n, int mode, int octaves, float persistence,
                                                          float lacunarity) {
-    __shared__ perm_t perm[1024];
+    __shared__ __attribute__((aligned(16))) perm_t perm[PERM_LDS_BYTES];
     load_perm(perm);
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
