@@ -501,9 +501,10 @@ def main():
         try:
             hi = renderer.hybrid_info()
             hybrid_note = (f"strict on {hi['strict_tiles']} of {hi['tiles']} 8x8 tiles (impact parameter within "
-                           f"[b_c - {hi['band_below']:g}, b_c + {hi['band_above']:g}] r_s of the photon sphere's 3 sqrt(3)/2), fast on the rest")
-        except Exception:      # a view that ran strict (anti-aliasing on)
-            hybrid_note = "this view runs strict (LOD anti-aliasing on)"
+                           f"[b_c - {hi['band_below']:g}, b_c + {hi['band_above']:g}] r_s of the photon sphere's 3 sqrt(3)/2), fast on the rest"
+                           + (f"; guards on, {hi['repaired_pixels']} pixels marched again strict" if hi.get("repair_capacity") else ""))
+        except Exception:      # no hybrid march has run on this context (a Disk V2 source or the persistent schedule: strict)
+            hybrid_note = "no hybrid march on this context: this view ran strict (Disk V2 source or persistent schedule)"
 
     # same scene, same process, the other arithmetics: reported beside the headline, never as `value`
     n_other = 0 if args.no_other_math else max(args.steps // 4, 10)

@@ -55,7 +55,8 @@ def parse_args(argv=None) -> argparse.Namespace:
                    help="march arithmetic.  strict: the reference's operations one by one with exactly rounded sqrt / divide "
                         "(ray paths bit-identical to an IEEE f32 evaluation of the reference).  hybrid (default): strict on the "
                         "8x8 tiles whose rays pass near the photon sphere, the fast arithmetic elsewhere -- within 3e-5 RMSE of "
-                        "strict, 1.7x faster; views with --anti_alias lod_radius run strict.  fast: v_rsq / v_rcp + fast-math "
+                        "strict, 1.7x faster; anti-aliased (--anti_alias lod_radius) and tilted views add guards to the fast tiles and "
+                        "march the pixels they flag again with the strict arithmetic.  fast: v_rsq / v_rcp + fast-math "
                         "everywhere (the analogue of Taichi's fast_math=True)")
     p.add_argument("--video_stream", type=str, default="auto", choices=["auto", "y4m", "off"],
                    help="--video: also hand the frames to the encoder as a yuv420p stream converted on the device "

@@ -1118,6 +1118,8 @@ __global__ __launch_bounds__(256) void march_fix_kernel(BhrMarchArgs a) {
     if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
     if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
     if (valid) ray.finish_at(a, pix % a.width, pix / a.width);
+    // the row-cost profile (BHR_ROW_COSTS): the guard kernel left these pixels' steps out, they are strict steps of their row band
+    if (a.row_steps && valid) atomicAdd(a.row_steps + (pix / a.width) / 8, (unsigned long long)ray.step_count);
     const unsigned long long tot = wave_sum_u32((unsigned int)ray.step_count);
     if (lane == 0) atomicAdd(a.ray_steps + (size_t)(blockIdx.x & (BHR_STEP_LANES - 1)) * BHR_STEP_STRIDE, tot);
 }

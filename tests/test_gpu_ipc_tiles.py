@@ -45,12 +45,12 @@ def test_one_process_per_tile_equals_one_context(tmp_path, world, gather, hip_li
     full = HipRenderer(640, 360, scenes.analytic_skybox(), scenes.noisy_disk(), frame_slots=1, **s["kw"])
     ref = full.render(s["cam_pos"], s["fov"])
     assert steps == full.counters()["ray_steps"]
+    # row blocks are bit-identical to the whole frame: the exact-f32 V pass adds a column's rows in ascending order
+    # whatever the tiling, the halo rows come through the IPC mappings as they were written
     if gather == "peer":
-        np.testing.assert_allclose(got, ref, atol=1e-6, rtol=0)
+        np.testing.assert_array_equal(got, ref)
     else:
-        want = full.read_final_u8()
-        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
-        assert d.max() <= 1 and (d > 0).mean() < 1e-4, (d.max(), (d > 0).mean())   # 1e-6 of bloom rounding across a truncation
+        np.testing.assert_array_equal(got, full.read_final_u8())
     full.close()
 
 
