@@ -19,7 +19,7 @@
 //   into the frame buffer directly all the same.
 // Two schedules, same bytes: serial (the V pass in one launch behind the wait) and pipelined (the rows at least R away
 // from a neighbouring block go through the V pass FIRST, under the neighbours' H passes / the halo pull).  Default:
-// pipelined where the tiles sit on distinct devices, serial where they share one.  The lens flare needs the frame's three
+// pipelined where there is a copy stage to hide (exact-f32 post-pass on distinct devices), serial otherwise.  The lens flare needs the frame's three
 // sums (a host read-back on tile 0), so with BHR_LENS_FLARE the tiles keep their f32 rows until the flare has been
 // applied and ship them with copies afterwards.
 //
@@ -284,7 +284,7 @@ int32_t set_mirrors(bhr_ctx **ctxs, int n, int k) {
 }
 
 int32_t render_tiles(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flags, float *out_host, const int32_t *live,
-                     bool threaded, bool pipelined) {
+                     bool threaded, int schedule) {
     const int with_bloom = (flags & BHR_SKIP_BLOOM) ? 0 : 1;
     const bool flare = (flags & BHR_LENS_FLARE) != 0;
     const bool gather = (flags & (BHR_GATHER_PEER | BHR_GATHER_U8)) != 0;
@@ -307,6 +307,14 @@ int32_t render_tiles(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flag
     if (halo)
         for (int k = 0; k < n; ++k)
             if (!live || live[k]) BHR_TRY(set_mirrors(ctxs, n, k));
+    // schedule < 0: by what there is to hide.  The exact-f32 post-pass PULLS its halo rows (a copy stage: worth running under
+    // the V pass of the middle rows on distinct devices); the split-f16 post-pass has none -- its neighbours' H kernels store
+    // the rows themselves -- and its V pass in ONE launch behind the wait is never later than in chunks: the frame ends with
+    // the slowest tile's own V pass either way, and one launch saves the chunks' fixed costs (~20 us per tile at 8k).
+    bool any_split = false;
+    for (int k = 0; k < n; ++k)
+        if (!live || live[k]) any_split = any_split || ctxs[k]->bloom_split != 0;
+    const bool pipelined = schedule >= 0 ? schedule != 0 : (schedule == -2 && !any_split);      // -2: tiles on distinct devices
 
     // phase 1: march and H pass (+ the neighbours' halo rows of a split frame) on the tile's stream
     BHR_TRY(for_tiles(n, live, threaded, [&](int k) -> int32_t {
@@ -459,13 +467,12 @@ int32_t bhr_group_render_subset(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam
     const bhr_options &opt = ctxs[0]->opt;
     bool threaded = n_live > 1 && distinct_devices;
     if (opt.group_threads >= 0) threaded = n_live > 1 && opt.group_threads != 0;              // BHR_GROUP_THREADS: test knob, force / forbid
-    // explicit flags win; without them BHR_GROUP_SCHEDULE decides, else: pipelined where the tiles sit on distinct devices
-    // (something to hide), serial where they share one (fewer launches)
-    bool pipelined = distinct_devices;
-    if (opt.group_schedule >= 0) pipelined = opt.group_schedule != 0;
-    if (flags & BHR_GROUP_SERIAL) pipelined = false;
-    else if (flags & BHR_GROUP_PIPELINED) pipelined = true;
-    return render_tiles(ctxs, n, cam, flags, out_host, live, threaded, pipelined);
+    // explicit flags win; without them BHR_GROUP_SCHEDULE decides, else render_tiles does (by post-pass and device layout)
+    int schedule = distinct_devices ? -2 : -1;
+    if (opt.group_schedule >= 0) schedule = opt.group_schedule != 0;
+    if (flags & BHR_GROUP_SERIAL) schedule = 0;
+    else if (flags & BHR_GROUP_PIPELINED) schedule = 1;
+    return render_tiles(ctxs, n, cam, flags, out_host, live, threaded, schedule);
 }
 
 int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host) {

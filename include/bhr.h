@@ -267,7 +267,8 @@ BHR_API int32_t bhr_set_outputs(bhr_ctx *ctx, uint32_t mask);
  *   "mip_lds"         BHR_MIP_LDS         1 anti-aliased fast frames stage the coarse mip levels in LDS
  *   "tile_order_rows" BHR_TILE_ORDER=row  1 row-major march launch order
  *   "group_threads"   BHR_GROUP_THREADS   -1 one submitting thread per tile where the tiles sit on distinct devices, 0 / 1 force
- *   "group_schedule"  BHR_GROUP_SCHEDULE  -1 by flags / device layout, 0 serial, 1 pipelined (explicit flags still win)
+ *   "group_schedule"  BHR_GROUP_SCHEDULE  -1 by flags, else pipelined where a halo copy can hide (exact-f32 post-pass on distinct
+ *                                         devices) and serial otherwise; 0 serial, 1 pipelined (explicit flags still win)
  * (bhr_create only: BHR_FRAME_SLOTS, BHR_TILE_BLOCK, BHR_AUX_STREAMS, BHR_STREAM_PAD.) */
 BHR_API int32_t bhr_set_option(bhr_ctx *ctx, const char *name, double value);
 /* Diagnostics (tests): the split-f16 post-pass's packed intermediates of the last frame as raw bytes -- which = 0 the H pass's

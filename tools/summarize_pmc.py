@@ -2,6 +2,12 @@
 import csv, glob, os, sys
 from collections import defaultdict
 
+def clean(name):
+    """'void (anonymous namespace)::bloom_h_split_kernel<5>((anonymous namespace)::HSplitArgs)' -> 'bloom_h_split_kernel<5>'"""
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "").strip()
+    return n.split("(")[0]
+
+
 def main():
     root = sys.argv[1]
     filt = sys.argv[2:] or ["bloom_"]
@@ -18,8 +24,8 @@ def main():
     for k in sorted(acc):
         if not any(s in k for s in filt):
             continue
-        short = k.split("(")[0][-60:]
-        d = next((v for n, v in dur.items() if n.split("(")[0] == k.split("(")[0] or k.startswith(n[:60])), None)
+        short = clean(k)
+        d = next((v for n, v in dur.items() if clean(n) == short), None)
         print(f"== {short}  calls/avg_us = {d}")
         for c in sorted(acc[k]):
             s, n = acc[k][c]

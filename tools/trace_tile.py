@@ -42,7 +42,7 @@ def main():
         multigpu.group_render(tiles, cam, fov, gather="peer_u8", schedule="pipelined")
     live = [1 if q == k else 0 for q in range(8)]
     for _ in range(6):
-        multigpu.group_render(tiles, cam, fov, gather="peer_u8", schedule="pipelined", live=live)
+        multigpu.group_render(tiles, cam, fov, gather="peer_u8", schedule="serial", live=live)
         time.sleep(0.002)
     print(blocks, tiles[k].counters()["frame_ms"])
     for x in tiles:
