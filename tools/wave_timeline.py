@@ -9,7 +9,8 @@ from bhr_amd import workloads
 
 path = "/tmp/wave_stamps.bin"
 wl = dict(width=1920, height=1080, cam_pos=[6, 0, 0.5], fov=90, step_size=0.1, disk_tilt=0.0, anti_alias="disabled")
-r, _, _, _ = workloads.make_scene(wl, frame_slots=1)
+math = sys.argv[1] if len(sys.argv) > 1 else None                 # strict (default) / fast: one launch; hybrid dumps its LAST launch (the fast list)
+r, _, _, _ = workloads.make_scene(wl, frame_slots=1, math=math)
 for _ in range(30):
     r.render_async(wl["cam_pos"], wl["fov"])
 r.sync()
@@ -47,7 +48,8 @@ for b in range(0, T + 1, B):
 # per SE/CU residency at the 450 us mark: which CUs are under-filled
 hw = w[:, 3].astype(np.int64)
 cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1
-mid = (t0 <= 45000) & (t1 >= 45000)
+mark = int(T // 2)
+mid = (t0 <= mark) & (t1 >= mark)
 key = se[mid] * 32 + sh[mid] * 16 + cu[mid]
 cnt = np.bincount(key, minlength=256)
-print("  waves alive at 450 us per (SE,SH,CU) id: min", cnt[cnt > 0].min(), "median", int(np.median(cnt[cnt > 0])), "max", cnt.max(), "ids seen", (cnt > 0).sum())
+print(f"  waves alive at {mark / 100:.0f} us per (SE,SH,CU) id: min", cnt[cnt > 0].min() if (cnt > 0).any() else 0, "median", int(np.median(cnt[cnt > 0])), "max", cnt.max(), "ids seen", (cnt > 0).sum())
