@@ -134,3 +134,31 @@ def test_march_busy_time_is_the_union_of_the_march_intervals(slots, hip_lib):
         assert c["march_busy_ms"] <= c["march_ms_sum"] * 1.001
         assert c["march_busy_ms"] < 0.98 * c["march_ms_sum"]         # the launches really overlap
     r.close()
+
+
+def test_slot_stream_calibration_is_invisible_in_the_frames(hip_lib):
+    """A two-slot context times six candidate streams for slot 1 once eight two-slot frames have been asked for
+    (csrc/api.hip: calibrate_slot_streams) -- ~500 extra renders of the ninth frame's view.  Nothing of it may show:
+    every frame before, at and after the calibration equals the one-slot context's, the ray-step and frame counters count
+    the caller's frames only, the report names the stream kept; option calibrate_streams 0 never calibrates."""
+    from bhr_amd import _lib
+    one, two, off = _mk(1, math="hybrid"), _mk(2, math="hybrid"), _mk(2, math="hybrid", options={"calibrate_streams": 0})
+    assert not two.stream_calibration()["done"]
+    two.timing_reset()
+    steps = 0
+    for k in range(14):
+        c, f = CAMS[k % len(CAMS)]
+        want = one.render(c, f)
+        steps += one.counters()["ray_steps"]
+        np.testing.assert_array_equal(two.render(c, f), want)
+        np.testing.assert_array_equal(off.render(c, f), want)
+        assert two.stream_calibration()["done"] == (k >= 8), k
+    cal = two.stream_calibration()
+    assert 0 <= cal["kept"] < 6 and max(cal["candidates_fps"]) > 0 and cal["candidates_fps"][cal["kept"]] > 0, cal
+    assert not off.stream_calibration()["done"]
+    c2 = two.counters()
+    assert c2["frames_timed"] == 14 and c2["ray_steps_sum"] == steps, (c2["frames_timed"], c2["ray_steps_sum"], steps)
+    m = two.stream_map()
+    assert set(m) >= {"scene+slot0", "scene+slot1", "slot0+slot1"} and all(isinstance(v, bool) for v in m.values())
+    for r in (one, two, off):
+        r.close()
