@@ -291,6 +291,20 @@ int32_t render_tiles(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flag
     bhr_ctx *head = ctxs[0];
     if (gather) BHR_TRY(ensure_gather(head, flags));
 
+    // The split-f16 post-pass stores halo rows straight into the neighbours' memory: every pair of tiles must be able to (peer
+    // access between their devices).  Where a pair cannot, the whole group falls back to the exact-f32 post-pass for this frame,
+    // whose halo rows travel by copies (staged through the host where there is no peer access): slower, still correct.
+    bool all_peer = true;
+    for (int k = 0; k < n && all_peer; ++k)
+        for (int q = 0; q < n && all_peer; ++q)
+            if (k != q && !peer_ok(ctxs[k], ctxs[q])) all_peer = false;
+    struct RestoreSplit {                     // the option is the context's own: put back whatever the frame does
+        bhr_ctx **c; int n; int32_t saved[64]; bool on;
+        ~RestoreSplit() { if (on) for (int k = 0; k < n && k < 64; ++k) c[k]->opt.bloom_split = saved[k]; }
+    } restore{ctxs, n, {}, !all_peer && n <= 64};
+    if (restore.on)
+        for (int k = 0; k < n; ++k) { restore.saved[k] = ctxs[k]->opt.bloom_split; ctxs[k]->opt.bloom_split = 0; }
+
     // every tile chooses its post-pass kernels and makes sure their buffers exist BEFORE any H pass may store into them
     for (int k = 0; k < n; ++k) {
         if (live && !live[k]) continue;
