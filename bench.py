@@ -588,7 +588,7 @@ def main():
         pixels = wl["width"] * wl["height"]
         alg_bytes = MARCH_BYTES_PER_PIXEL * pixels
         achieved_gbs = alg_bytes / (march_ms * 1e-3) / 1e9
-        traffic = traffic_source = None
+        traffic = traffic_source = executed_flop = None
         tpath = os.path.join(ROOT, "profiles", "march_traffic.json")
         if os.path.isfile(tpath):
             try:
@@ -596,6 +596,8 @@ def main():
                 key = f"{args.workload}/{renderer.math}"
                 traffic = tj.get(key, tj.get(args.workload) if renderer.math == "strict" else None)
                 traffic_source = (tj.get("source", "") + f"; key {key}: " + json.dumps(tj.get(f"_{key}_detail", tj.get(f"_{args.workload}_detail")))) if traffic else None
+                det = tj.get(f"_{key}_detail") or {}
+                executed_flop = det.get("executed_fp32_flop_per_frame")
             except Exception:
                 traffic = None
         valu_tflops = MARCH_FLOP_PER_RAY_STEP * k_steps / (march_ms * 1e-3) / 1e12
@@ -645,7 +647,13 @@ def main():
             # the march is not HBM bound: the governing ceiling is non-matrix FP32
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_FP32_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": valu_tflops / VALU_FP32_PEAK_TFLOPS,
-                              "flop_per_ray_step": MARCH_FLOP_PER_RAY_STEP},
+                              "flop_per_ray_step": MARCH_FLOP_PER_RAY_STEP,
+                              # what the kernels EXECUTE (the 205 above is the reference's 3-D formulation; the fast list marches in
+                              # the 2-D orbital plane): 64 x (2 FMA + MUL + ADD wave-instructions) of the march kernels, from the
+                              # PMC pass of the profile named in roofline.traffic_source, over this run's march time
+                              "executed_flop_per_frame": executed_flop,
+                              "executed_tflops": (executed_flop / (march_ms * 1e-3) / 1e12) if executed_flop else None,
+                              "executed_frac": (executed_flop / (march_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS) if executed_flop else None},
         }
         if others:
             out["other_math"] = {"runs": others,

@@ -74,12 +74,27 @@ if traffic_args:
                 n[k] += 1
         frames = max(n.values())                     # a hybrid march is two kernels per frame: their bytes add up
         vals[name] = ({k: round(tot[k] / n[k], 1) for k in n}, sum(tot.values()) / frames, frames)
+    # FP32 flop the march kernels execute per frame: 64 lanes x (2 x FMA + MUL + ADD wave-instructions), pmc_b pass
+    flop = None
+    try:
+        f = find("pmc_b", "counter_collection.csv")
+        tot, n = defaultdict(float), defaultdict(int)
+        for r in csv.DictReader(open(f)):
+            if "march" in r["Kernel_Name"] and r["Counter_Name"] in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32"):
+                tot[r["Counter_Name"]] += float(r["Counter_Value"])
+                n[(short(r["Kernel_Name"]), r["Counter_Name"])] += 1
+        frames_b = max(n.values()) if n else 0
+        if frames_b:
+            flop = 64.0 * (2.0 * tot["SQ_INSTS_VALU_FMA_F32"] + tot["SQ_INSTS_VALU_MUL_F32"] + tot["SQ_INSTS_VALU_ADD_F32"]) / frames_b
+    except Exception:
+        flop = None
     tj = json.load(open(path)) if os.path.isfile(path) else {}
     tj[workload] = (vals["FETCH_SIZE"][1] + vals["WRITE_SIZE"][1]) * 1024.0
     tj[f"_{workload}_detail"] = {"kernels_FETCH_SIZE_KiB_per_launch": vals["FETCH_SIZE"][0], "kernels_WRITE_SIZE_KiB_per_launch": vals["WRITE_SIZE"][0],
                                  "FETCH_SIZE_KiB_per_frame": vals["FETCH_SIZE"][1], "WRITE_SIZE_KiB_per_frame": vals["WRITE_SIZE"][1],
                                  "frames": vals["FETCH_SIZE"][2],
                                  "profile": f"profiles/{os.path.basename(out).replace('prof_', '')}.md",
+                                 "executed_fp32_flop_per_frame": flop,
                                  "commit": os.environ.get("BHR_COMMIT", "unknown")}
     tj["source"] = "tools/summarize_prof.py from the pmc_fetch / pmc_write CSVs of tools/profile.sh; per workload/math: _<key>_detail"
     tj["_note"] = ("HBM bytes per march (all its launches of one frame) from rocprofv3 --pmc (separate passes): (FETCH_SIZE + WRITE_SIZE) KiB x 1024. "
