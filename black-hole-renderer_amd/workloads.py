@@ -145,7 +145,7 @@ def make_tiles(wl: dict, devices, n_stars: int = 6000, math=None, balance: bool 
                 t.render_async(wl["cam_pos"], wl["fov"])
                 one.append(t.counters()["frame_ms"])
             ms.append(float(np.median(one)))
-            t.set_outputs("f32+blur+u8")
+            t.set_outputs("f32")                                    # the library's default
         ms = np.array(ms)
         if ms.min() >= 0.15 and ms.max() > 1.03 * ms.mean():
             blocks2, _ = rebalance(wl["height"], n, blocks, per_row, ms)
