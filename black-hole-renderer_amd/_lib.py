@@ -14,7 +14,7 @@ BHR_OK = 0
 BHR_ERR_INVALID, BHR_ERR_NO_DEVICE, BHR_ERR_HIP, BHR_ERR_STATE, BHR_ERR_NOMEM = -1, -2, -3, -4, -5
 
 SKIP_DIFFERENTIALS, SKIP_BLOOM, PERSISTENT, FORCE_FAST, FORCE_STRICT, LENS_FLARE, ROW_COSTS, GATHER_PEER = 1, 2, 4, 8, 16, 32, 64, 128
-FORCE_HYBRID, GATHER_U8, GROUP_SERIAL, GROUP_PIPELINED, GROUP_TIME_MARCH = 256, 512, 1024, 2048, 4096
+FORCE_HYBRID, GATHER_U8, GROUP_SERIAL, GROUP_PIPELINED, GROUP_TIME_MARCH, GROUP_ASYNC = 256, 512, 1024, 2048, 4096, 8192
 MATH_FAST, MATH_STRICT, MATH_HYBRID = 0, 1, 2
 LAYER_FINAL, LAYER_BG, LAYER_DISK, LAYER_BLUR = 0, 1, 2, 3
 OUTPUT_F32, OUTPUT_BLUR, OUTPUT_U8 = 1, 2, 4
@@ -25,7 +25,7 @@ SYMBOLS = (
     "bhr_set_skybox", "bhr_skybox_add_glow", "bhr_skybox_build", "bhr_get_skybox", "bhr_set_disk_texture", "bhr_get_disk_texture", "bhr_get_disk_mip", "bhr_num_mip_levels",
     "bhr_bg_init", "bhr_generate_background", "bhr_set_entity_staging", "bhr_set_comp", "bhr_read_comp",
     "bhr_fill_comp_slice", "bhr_set_compose_stats", "bhr_compose_texture", "bhr_eval_noise", "bhr_render",
-    "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_set_outputs", "bhr_set_option", "bhr_debug_read", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_get_row_costs_split", "bhr_mip_lds_level", "bhr_hybrid_info", "bhr_hybrid_repairs", "bhr_timing_reset", "bhr_timing_dump", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_group_render_subset", "bhr_read_gathered", "bhr_read_gathered_u8", "bhr_tile_export", "bhr_tile_connect", "bhr_tile_render", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities", "bhr_accumulate_population",
+    "bhr_read_layer", "bhr_write_layer", "bhr_bloom", "bhr_set_outputs", "bhr_set_option", "bhr_debug_read", "bhr_lens_flare", "bhr_lens_flare_sums", "bhr_read_final_u8", "bhr_get_counters", "bhr_get_row_costs_split", "bhr_mip_lds_level", "bhr_hybrid_info", "bhr_hybrid_repairs", "bhr_timing_reset", "bhr_timing_dump", "bhr_get_row_costs", "bhr_selftest", "bhr_group_render", "bhr_group_render_subset", "bhr_group_sync", "bhr_read_gathered", "bhr_read_gathered_u8", "bhr_tile_export", "bhr_tile_connect", "bhr_tile_render", "bhr_disk_v2_eval", "bhr_set_disk_source", "bhr_set_disk_volume_options", "bhr_entity_profile_upload", "bhr_entity_profile_reset", "bhr_accumulate_entities", "bhr_accumulate_population",
     "bhr_stats_prepare", "bhr_stats_select", "bhr_stats_row_statistics",
     "bhr_png_bound", "bhr_png_encode", "bhr_png_write", "bhr_png_device_bound", "bhr_png_device_max_width", "bhr_png_encode_device", "bhr_png_device_menu",
     "bhr_sink_create", "bhr_sink_submit", "bhr_sink_drain",
@@ -133,6 +133,7 @@ def load() -> C.CDLL:
     lib.bhr_selftest.argtypes = [P, C.POINTER(C.c_uint64)]
     lib.bhr_group_render.argtypes = [C.POINTER(P), I32, C.POINTER(Camera), C.c_uint32, F]
     lib.bhr_group_render_subset.argtypes = [C.POINTER(P), I32, C.POINTER(Camera), C.c_uint32, F, C.POINTER(C.c_int32)]
+    lib.bhr_group_sync.argtypes = [C.POINTER(P), I32]
     lib.bhr_read_gathered_u8.argtypes = [P, C.POINTER(C.c_uint8)]
     lib.bhr_tile_export.argtypes = [P, C.c_uint32, C.POINTER(TileHandles)]
     lib.bhr_tile_connect.argtypes = [P, I32, I32, C.POINTER(TileHandles), C.POINTER(C.c_uint64)]

@@ -41,7 +41,8 @@ constexpr int PIPE_MAX_CHUNKS = 16;
 
 struct TilePipe {
     hipStream_t copy;             // halo pulls of the exact-f32 post-pass
-    hipEvent_t halo_ready, halo_in;
+    hipEvent_t halo_ready, halo_in, frame_done;   // frame_done: the tile's last kernel of its last group frame
+    int32_t in_flight;            // that frame was submitted with BHR_GROUP_ASYNC and nobody has waited for it yet
     // one-process-per-tile variant (bhr_tile_connect): the neighbours' planes and tile 0's frame buffers, opened from their
     // IPC handles; counters in host shared memory for the hand-shakes
     int32_t linked, rank, world, split;
@@ -72,7 +73,7 @@ int32_t ensure_pipe(bhr_ctx *ctx) {
     memset(p, 0, sizeof(*p));
     ctx->pipe = p;
     BHR_HIP(hipStreamCreateWithFlags(&p->copy, hipStreamNonBlocking));
-    hipEvent_t *evs[] = {&p->halo_ready, &p->halo_in};
+    hipEvent_t *evs[] = {&p->halo_ready, &p->halo_in, &p->frame_done};
     for (hipEvent_t *ev : evs) BHR_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     return BHR_OK;
 }
@@ -336,6 +337,13 @@ int32_t render_tiles(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flag
         BHR_HIP(hipSetDevice(c->cfg.device));
         TilePipe *p = (TilePipe *)c->pipe;
         BHR_TRY(bhr_launch_march(c, cam, flags));
+        // frames in flight (BHR_GROUP_ASYNC): this H pass stores into its neighbours' halo rows, which their previous frame's V
+        // passes may still be reading -- wait for those on the device
+        if (with_bloom && c->bloom_split)
+            for (int q = 0; q < n; ++q) {
+                TilePipe *pq = q == k ? nullptr : (TilePipe *)ctxs[q]->pipe;
+                if (pq && pq->in_flight && needs_rows_of(ctxs[q], c, 16 * (bhr_split_nt(c->bloom_R) - 1) + 32)) BHR_HIP(hipStreamWaitEvent(c->stream, pq->frame_done, 0));
+            }
         if (with_bloom) BHR_TRY(bhr_launch_bloom_h(c));
         // `halo_ready` (this tile's H pass is done: its neighbours may run the V pass of their edge rows).  An event record is a
         // ~5 us bubble in the stream: the pipelined schedule records it BEHIND the V pass of the middle rows (phase 3) -- the
@@ -417,6 +425,25 @@ int32_t render_tiles(bhr_ctx **ctxs, int n, const bhr_camera *cam, uint32_t flag
         BHR_HIP(hipSetDevice(ctxs[k]->cfg.device));
         BHR_HIP(hipEventRecord(ctxs[k]->ev[2], ctxs[k]->stream));      // frame_ms = first march launch .. rows landed
     }
+    // BHR_GROUP_ASYNC: where the kernels themselves have stored everything the frame produces, the call ends here; the frame
+    // buffer's owner waits for every tile on the DEVICE, so whatever is queued on its stream next (bhr_read_gathered*) sees
+    // the whole frame
+    bool async = (flags & BHR_GROUP_ASYNC) && gather && !flare && !out_host && with_bloom;
+    for (int k = 0; k < n && async; ++k)
+        if ((!live || live[k]) && (!ctxs[k]->bloom_split || !peer_ok(ctxs[k], head))) async = false;
+    for (int k = 0; k < n; ++k) {
+        if (live && !live[k]) continue;
+        TilePipe *p = (TilePipe *)ctxs[k]->pipe;
+        BHR_HIP(hipSetDevice(ctxs[k]->cfg.device));
+        BHR_HIP(hipEventRecord(p->frame_done, ctxs[k]->stream));
+        p->in_flight = async ? 1 : 0;
+    }
+    if (async) {
+        BHR_HIP(hipSetDevice(head->cfg.device));
+        for (int k = 0; k < n; ++k)
+            if ((!live || live[k]) && ctxs[k] != head) BHR_HIP(hipStreamWaitEvent(head->stream, ((TilePipe *)ctxs[k]->pipe)->frame_done, 0));
+        return BHR_OK;
+    }
     return finish(ctxs, n, live, out_host);
 }
 
@@ -446,7 +473,7 @@ void bhr_pipe_free(bhr_ctx *ctx) {
     if (!p) return;
     close_mappings(ctx, p);
     if (p->copy) (void)hipStreamDestroy(p->copy);
-    hipEvent_t evs[] = {p->halo_ready, p->halo_in};
+    hipEvent_t evs[] = {p->halo_ready, p->halo_in, p->frame_done};
     for (hipEvent_t ev : evs)
         if (ev) (void)hipEventDestroy(ev);
     delete p;
@@ -491,6 +518,17 @@ int32_t bhr_group_render_subset(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam
 
 int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host) {
     return bhr_group_render_subset(ctxs, n, cam, flags, out_host, nullptr);
+}
+
+int32_t bhr_group_sync(bhr_ctx **ctxs, int32_t n) {
+    if (!ctxs || n <= 0) return bhr_fail(BHR_ERR_INVALID, "bhr_group_sync: bad argument");
+    for (int k = 0; k < n; ++k) {
+        if (!ctxs[k]) return bhr_fail(BHR_ERR_INVALID, "bhr_group_sync: null context %d", k);
+        BHR_HIP(hipSetDevice(ctxs[k]->cfg.device));
+        BHR_HIP(hipStreamSynchronize(ctxs[k]->stream));
+        if (ctxs[k]->pipe) ((TilePipe *)ctxs[k]->pipe)->in_flight = 0;
+    }
+    return BHR_OK;
 }
 
 // ---- one process per tile (bench.py --strong under torchrun when a rank sees only its own GPU) -------------------------

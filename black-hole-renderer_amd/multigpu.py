@@ -102,7 +102,7 @@ def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
 
 def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_differentials=False,
                  skip_bloom=False, lens_flare=False, gather: str = "host", schedule: str = "auto", live=None,
-                 time_march: bool = False):
+                 time_march: bool = False, wait: bool = True):
     """Render one frame with the row-block renderers ``tiles`` (HipRenderer objects whose rows tile
     the image in order).  gather="host": returns the (H, W, 3) float32 frame, assembled from per-device pinned
     buffers.  gather="peer": every tile's V pass stores its f32 rows straight into the frame buffer on tiles[0]'s device
@@ -112,7 +112,10 @@ def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_diff
     csrc/group.hip), "serial" (one V launch behind the wait; same bytes) or "auto" (default: pipelined where the
     tiles sit on distinct devices, serial where they share one).  live: per-tile 0/1 -- only those tiles render, the
     others keep the buffers of the last call in which they did (bench.py times one tile of eight that way).
-    time_march: also record every tile's march-end event (counters()["march_ms"]; a ~5 us bubble in the tile's stream)."""
+    time_march: also record every tile's march-end event (counters()["march_ms"]; a ~5 us bubble in the tile's stream).
+    wait=False (gather "peer" / "peer_u8" of frames whose rows the kernels store themselves): return once the frame is
+    submitted -- the next one may follow at once, the tiles order themselves on the device (BHR_GROUP_ASYNC);
+    group_sync(tiles), read_gathered*(tiles) or any waiting call ends the frames in flight."""
     if gather not in ("host", "peer", "peer_u8", "none"):
         raise ValueError(f"gather must be 'host', 'peer', 'peer_u8' or 'none', got {gather!r}")
     if schedule not in ("auto", "pipelined", "serial"):
@@ -128,6 +131,8 @@ def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_diff
     flags |= {"host": 0, "none": 0, "peer": _lib.GATHER_PEER, "peer_u8": _lib.GATHER_U8}[gather]
     if time_march:
         flags |= _lib.GROUP_TIME_MARCH
+    if not wait:
+        flags |= _lib.GROUP_ASYNC
     live_arr = None
     if live is not None:
         if len(live) != len(tiles):
@@ -139,6 +144,12 @@ def group_render(tiles: Sequence, cam_pos, fov: float, frame: int = 0, skip_diff
     out = np.empty((first.height, first.width, 3), dtype=np.float32)
     _lib.check(lib.bhr_group_render_subset(arr, len(tiles), C.byref(cam), flags, _lib.fptr(out), live_arr))
     return out
+
+
+def group_sync(tiles: Sequence) -> None:
+    """Wait for every group frame the tiles have in flight (group_render(..., wait=False))."""
+    arr = (C.c_void_p * len(tiles))(*[t._ctx for t in tiles])
+    _lib.check(_lib.load().bhr_group_sync(arr, len(tiles)))
 
 
 def read_gathered(tiles: Sequence) -> np.ndarray:

@@ -115,6 +115,12 @@ typedef struct {
 #define BHR_GROUP_PIPELINED 2048u  /* bhr_group_render: the pipelined schedule (halo pull under the V pass of the middle rows, row
                                       chunks pushed while the next chunk's V kernel runs).  Neither flag: pipelined where the
                                       tiles sit on distinct devices, serial where they share one */
+#define BHR_GROUP_ASYNC     8192u  /* bhr_group_render: return once the frame is SUBMITTED (frames whose rows are stored by the kernels
+                                      themselves: a GATHER flag, split-f16 post-pass, no lens flare, no host output; any other frame
+                                      synchronises as before).  The next frame may be submitted at once: a tile's H pass waits, on
+                                      the device, for its neighbours' previous V passes before it stores into their halo rows.
+                                      bhr_group_sync / bhr_read_gathered* / any synchronous call waits for the frames in flight;
+                                      per-tile counters describe the LAST frame submitted */
 #define BHR_GROUP_TIME_MARCH 4096u /* bhr_group_render / bhr_tile_render: also record every tile's march-end event (bhr_counters.march_ms /
                                       bloom_ms of the tiles; frame_ms is always available).  Off by default: the record is a ~5 us bubble
                                       between the march and the H pass of every tile */
@@ -336,6 +342,8 @@ BHR_API int32_t bhr_group_render(bhr_ctx **ctxs, int32_t n, const bhr_camera *ca
  * device (bench.py tile_scaling): its counters' frame_ms then spans first march launch .. its rows landed on tile 0. */
 BHR_API int32_t bhr_group_render_subset(bhr_ctx **ctxs, int32_t n, const bhr_camera *cam, uint32_t flags, float *out_host,
                                         const int32_t *live);
+/* Waits for every frame the tiles have in flight (BHR_GROUP_ASYNC). */
+BHR_API int32_t bhr_group_sync(bhr_ctx **ctxs, int32_t n);
 /* The quantised frame the last bhr_group_render(..., BHR_GATHER_U8) gathered on this context's device: (H, W, 3) u8. */
 BHR_API int32_t bhr_read_gathered_u8(bhr_ctx *ctx, uint8_t *out);
 

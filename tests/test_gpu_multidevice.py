@@ -178,3 +178,42 @@ def test_bench_row_block_leg_in_a_child_process(hip_lib):
     assert t.get("n_gpus") == 1 and t["frames"] == 4 and t["value"] > 0 and len(t["row_blocks"]) == 1, t
     bad = bench.tile_leg_in_child("fhd", 3, 4, "hybrid")        # three devices on a one-GPU box: skipped, not an error
     assert "skipped" in bad or "error" in bad, bad
+
+
+@pytest.mark.parametrize("math", ["hybrid", "fast"])
+def test_group_frames_in_flight_equal_frames_waited_for(math, hip_lib):
+    """BHR_GROUP_ASYNC (group_render(..., wait=False)): frames whose rows the kernels store themselves are submitted back to
+    back, nothing on the host waits between them; a tile's H pass waits on the device for its neighbours' previous V passes
+    before it stores into their halo rows.  Views alternate so that a halo row written too early, or a frame row of the wrong
+    frame, would show: after every burst the gathered frame equals the waited-for frame of the burst's LAST view, and one
+    context's; read_gathered_u8 alone (no group_sync) sees the whole last frame."""
+    from bhr_amd import HipRenderer, multigpu
+    W, H = 1920, 1080
+    sky, tex = scenes.analytic_skybox(256, 512), scenes.noisy_disk(256, 1024)
+    kw = dict(step_size=0.1, r_max=10.0, r_disk_inner=2.0, r_disk_outer=15.0, disk_tilt=0.0)
+    views = [([6.0, 0.0, 0.5], 90.0), ([5.0, 2.0, 1.0], 80.0), ([-7.0, 1.0, 0.3], 70.0)]
+    blocks = [(0, 312), (312, 544), (544, 800), (800, 1080)]
+    tiles = [HipRenderer(W, H, sky, tex, rows=b, frame_slots=1, math=math, **kw) for b in blocks]
+    want = []
+    for cam, fov in views:
+        multigpu.group_render(tiles, cam, fov, gather="peer_u8")
+        want.append(multigpu.read_gathered_u8(tiles).copy())
+    assert not np.array_equal(want[0], want[1])
+    full = HipRenderer(W, H, sky, tex, frame_slots=1, math=math, **kw)
+    full.render_async(*views[2])
+    np.testing.assert_array_equal(want[2], full.read_final_u8())
+    full.close()
+    for burst in range(3):
+        for k in range(7):
+            cam, fov = views[(k + burst) % 3]
+            multigpu.group_render(tiles, cam, fov, gather="peer_u8", wait=False)
+        last = (6 + burst) % 3
+        if burst == 1:
+            multigpu.group_sync(tiles)
+        np.testing.assert_array_equal(multigpu.read_gathered_u8(tiles), want[last])
+    # a waited-for frame behind frames in flight
+    multigpu.group_render(tiles, *views[0], gather="peer_u8", wait=False)
+    multigpu.group_render(tiles, *views[1], gather="peer_u8")
+    np.testing.assert_array_equal(multigpu.read_gathered_u8(tiles), want[1])
+    for t in tiles:
+        t.close()
