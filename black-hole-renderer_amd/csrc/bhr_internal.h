@@ -25,8 +25,8 @@
 // Ray-step counters: every wave adds its count with one atomic.  32 400 atomics to ONE address serialise in
 // the memory system and put a floor of 0.45 ms under an fhd launch (measured; the fast march spends 0.36 ms);
 // a counter is therefore a cell of 128 lanes, 256 bytes apart, indexed by block, summed when read.
-// rows of zeros in front of and behind the (3, rows + 2R, W) H-blur planes: the bf16 V pass walks input rows in chunks
-// aligned to global multiples of 16 and reads up to 15 rows past either end (zero weights; bloom.hip)
+// rows of zeros in front of and behind the (3, rows + 2R, W) H-blur planes of the exact-f32 post-pass (the IPC handles of
+// csrc/group.hip name the allocation: the planes start this many rows in)
 #define BHR_HBLUR_PAD_ROWS 16
 #define BHR_STEP_LANES 128
 #define BHR_STEP_STRIDE 32          // in u64 words

@@ -15,7 +15,7 @@ def main():
     from bhr_amd import HipRenderer, multigpu, scenes
     s = scenes.SCENES["default"]
     W, H = 640, 360                                        # R = 12: tiles of 360 / world rows are thicker than the halo
-    if os.environ.get("BHR_TEST_SIZE"):                     # e.g. 960x544: radius 19, the bf16 V pass under fast / hybrid
+    if os.environ.get("BHR_TEST_SIZE"):                     # e.g. 960x544: radius 19, the split-f16 post-pass under fast / hybrid
         W, H = (int(v) for v in os.environ["BHR_TEST_SIZE"].split("x"))
     cuts = [round(H * k / world / 8) * 8 for k in range(world)] + [H]
     sky, tex = scenes.analytic_skybox(), scenes.noisy_disk()

@@ -54,8 +54,8 @@ def test_one_process_per_tile_equals_one_context(tmp_path, world, gather, hip_li
     full.close()
 
 
-def test_one_process_per_tile_hybrid_with_the_bf16_v_pass(tmp_path, hip_lib):
-    """960x544 (bloom radius 19), hybrid: every process marches its block's strict and fast tile lists and runs the bf16 V
+def test_one_process_per_tile_hybrid_with_the_split_post_pass(tmp_path, hip_lib):
+    """960x544 (bloom radius 19), hybrid: every process marches its block's strict and fast tile lists and runs the split-f16 V
     pass over halo rows that arrived through IPC handles -- the same bits as one hybrid context."""
     from bhr_amd import HipRenderer
     got, steps = _run(tmp_path, 3, "peer", math="hybrid", size=(960, 544))
