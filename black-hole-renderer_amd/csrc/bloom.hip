@@ -780,6 +780,14 @@ SplitPlan plan_segments(int n_tiles, long long others, int NT, int forced_tiles)
         const int sf = min(min(forced_tiles, 8), n_tiles);
         return SplitPlan{sf > 5 ? 8 : 5, (n_tiles + sf - 1) / sf, sf};
     }
+    // a launch that fits ONE round of workgroup slots even at five tiles per wave: five it is -- such a launch is not short of
+    // slots, and fewer, longer waves stage the weight table and re-read the bands' overlap less often (fhd, both passes:
+    // 0.0372 against 0.0406 ms with the four / three tiles per wave the round model below prefers; `bloom_tiles` sweep)
+    {
+        const int n_seg5 = (n_tiles + 4) / 5, sg5 = (n_tiles + n_seg5 - 1) / n_seg5;
+        const long long groups5 = (others * ((n_tiles + sg5 - 1) / sg5) + SPLIT_SUBS - 1) / SPLIT_SUBS;
+        if (groups5 <= 512) return SplitPlan{5, (n_tiles + sg5 - 1) / sg5, sg5};
+    }
     SplitPlan best{5, n_tiles, 1};
     double best_cost = 1e300;
     long long best_rounds = 1;
