@@ -721,17 +721,25 @@ struct Ray {
 // factor r/|z| there, measured as 2x the parity error).  Ray differentials split into an in-plane
 // pair coupled through the projection term of the Jacobian and an out-of-plane component that
 // sees only the isotropic term:  J d = c (d - 5 s (s.d)/r^2).
+//
+// The ray's own clock (round 4).  Every ray marches in an affine parameter of its own, lambda' = lambda / tau with
+// tau^2 (1.5 L2) = 1: the equation of motion becomes u'' = -u / r^5 -- no coefficient to multiply in at the four radii of
+// a step (c = -(1/r)^5 straight from the v_rsq) -- with velocities tau x direction and the step h_base dt_fac / tau (a
+// per-lane factor in a vector register: a product with the scalar h_base issues at half rate).  RK4 is invariant
+// under the rescaling, so the sequence of positions is the reference's up to rounding; tau carries a relative rounding
+// error of ~1e-7 into the force constant, the size of the rounding of L2 itself.  Positions stay in r_s.
 // =============================================================================
 template <bool DIFF, int SRC = 0>
 struct Ray {
-    float u, w, du, dw;   // position / direction along (g1, g2)
-    float m15L2;          // -1.5 * L2
-    float ir;             // 1/|p|
-    float c1;             // acceleration coefficient at p:  -1.5 L2 / r^5
-    float f_old;          // plane function at p
-    float Bn;             // n . g2
+    float u, w, du, dw;   // position / velocity (tau x direction) along (g1, g2)
+    float hk;             // h_base / tau: step = dt_fac hk
+    float ij;             // 1 / |(u, w)|
+    float c1;             // acceleration coefficient at (u, w):  -1 / r^5
+    float esc2;           // r_escape^2, in a vector register (an SGPR operand halves the v_med3's issue rate)
+    float Bn;             // n . g2: the plane function z - y tan(tilt) is Bn w
     V3 g1, g2;            // in-plane orthonormal basis
-    float affine;
+    bool full;            // wave-uniform: some live lane has both its parking slots occupied
+    float affine;         // in units of h_base
     Shade sh;
     int n_pend;    // parked disk crossings (0..2), in the lane's LDS slots, oldest first
     int step_count;
@@ -747,7 +755,12 @@ struct Ray {
         // L2 exactly as the reference forms it (render.py:2828)
         V3 Lv = cross(d0, p0);
         float L2 = dot(Lv, Lv);
-        m15L2 = -1.5f * L2;
+        // tau = (1.5 L2)^(-1/2), v_rsq + one Newton step.  A radial ray (L2 -> 0: no deflection at all) marches with the
+        // force of L2 ~ 1e-12: below the rounding of its velocity
+        const float kap = fmaxf(1.5f * L2, 1e-12f);
+        float tau = q_rsq(kap);
+        tau = tau * fmaf(-0.5f * kap, tau * tau, 1.5f);
+        hk = a.h_base * (kap * tau);
         // unit normal of the orbital plane; for a radial ray (L = 0) any direction orthogonal to p0
         V3 e3;
         if (L2 > 1e-20f) {
@@ -771,12 +784,17 @@ struct Ray {
         Bn = dot(n, g2);
         u = dot(p0, g1);
         w = dot(p0, g2);
-        du = dot(d0, g1);
-        dw = dot(d0, g2);
-        ir = 1.0f / a.r0;
-        float i2 = ir * ir;
-        c1 = m15L2 * (i2 * i2 * ir);
-        f_old = Bn * w;
+        du = tau * dot(d0, g1);
+        dw = tau * dot(d0, g2);
+        ij = 1.0f / a.r0;
+        float i2 = ij * ij;
+        c1 = -(i2 * i2 * ij);
+#ifdef BHR_ESC2_SGPR
+        esc2 = a.r_esc2;
+#else
+        asm volatile("v_mov_b32 %0, %1" : "=v"(esc2) : "s"(a.r_esc2));
+#endif
+        full = false;
         affine = 0.0f;
         sh.accum = mk(0, 0, 0);
         sh.alpha_total = 0.0f;
@@ -786,19 +804,19 @@ struct Ray {
         done = a.max_iter <= 0 ? 3 : 0;
         pix = j_local * a.width + i;
         if (DIFF) {
-            ddx = mk(dot(gx, g1), dot(gx, g2), dot(gx, e3));
-            ddy = mk(dot(gy, g1), dot(gy, g2), dot(gy, e3));
+            ddx = mk(tau * dot(gx, g1), tau * dot(gx, g2), tau * dot(gx, e3));
+            ddy = mk(tau * dot(gy, g1), tau * dot(gy, g2), tau * dot(gy, e3));
             dpx = mk(0, 0, 0);
             dpy = mk(0, 0, 0);
         }
     }
 
-    // coefficient c(s) = -1.5 L2 / r^5 and 1/r^2 at the in-plane point (su, sw)
+    // coefficient c(s) = -1 / r^5 and 1/r^2 at the in-plane point (su, sw)
     __device__ __forceinline__ float coef(float su, float sw, float &i2) const {
         float r2 = fmaf(su, su, sw * sw);
         float i1 = q_rsq(r2);
         i2 = i1 * i1;
-        return m15L2 * (i2 * i2 * i1);
+        return -(i2 * i2 * i1);
     }
     // J(s) delta with delta = (in-plane u, in-plane w, out-of-plane n)
     __device__ __forceinline__ V3 jac(float su, float sw, V3 dl, float c, float i2) const {
@@ -832,10 +850,10 @@ struct Ray {
         // = rsq(max(q, 0.01)), near_damp = 1 / (1 + 2 q^3), so far_scale near_damp = rsq(max(q, 0.01) (1 + 2 q^3)^2).  The
         // reference's clamp to [0.2, 10] never binds: q <= 1 / 1.001 gives far_scale >= 1 and near_damp > 1/3, and the
         // product is <= far_scale <= 10.  (Round 3: v_rsq + v_rcp, 12.7 issue cycles each inside this instruction mix.)
-        float q = fminf(ir, 1.0f / (BHR_RS + 1e-3f));
+        float q = fminf(ij, 1.0f / (BHR_RS + 1e-3f));
         float nd = fmaf(2.0f * q, q * q, 1.0f);
         float dt_fac = q_rsq(fmaxf(q, 0.01f) * (nd * nd));
-        float h = a.h_base * dt_fac;       // (h_base in a vector register would save 2 issue cycles and cost the plain kernel its sixth wave: 80 -> 90 VGPRs)
+        float h = dt_fac * hk;             // in the ray's own clock
         float hh = 0.5f * h;
         float h6 = h * (1.0f / 6.0f);
 
@@ -859,14 +877,19 @@ struct Ray {
         float sdw = fmaf(c4, s4w, a1w) + 2.0f * (a2w + a3w);
 
         float r2n = fmaf(nu, nu, nw * nw);
-        // the affine parameter is kept in units of h_base: one plain v_add per step instead of an FMA with a scalar operand
-        // (half rate), compared against max_affine / h_base
+        // the affine parameter is kept in units of h_base: one plain v_add per step, compared against max_affine / h_base
         float aff = affine + dt_fac;
-        // termination precedes the plane test (render.py:2916-2926); r < 1  <=>  r^2 < 1 etc.
-        const bool captured = r2n < BHR_RS * BHR_RS;
-        const bool escaped = !captured && (r2n > a.r_esc2 || aff > a.max_affine_u);
-        const bool alive = !captured && !escaped;
-        float f_new = Bn * nw;
+        // termination precedes the plane test (render.py:2916-2926); r < r_s  <=>  r^2 < r_s^2 etc.  One v_med3 and one
+        // compare for the two radii (a compare costs two plain instructions' issue time): the ray goes on iff
+        // r_s^2 <= r^2 <= r_esc^2, the same strict inequalities as the reference's.  Which of the two ended it is worked
+        // out once, behind the loop (escaped()).
+        const bool ended = __builtin_amdgcn_fmed3f(r2n, BHR_RS * BHR_RS, esc2) != r2n || aff > a.max_affine_u;
+        const bool alive = !ended;
+        // The plane function is Bn w: its sign changes where w's does, so the loop carries no plane function and no Bn (two
+        // registers and a multiplication per step); the reference's own test, on the products, is made inside the
+        // wave-uniform branch below (it also keeps a ray that lies IN the disk plane, Bn = 0, from ever crossing it).
+        const bool crossing = w * nw < 0;
+        const float f_old = Bn * w, f_new = Bn * nw;     // (dead in the kernels that read no guard flag)
         // Discontinuity guard (read by the hybrid kernel only): a step that crosses the disk plane registers the hit only
         // if it does not also end the ray (render.py:2916-2934) -- with a disk wider than the escape sphere that is a hit /
         // no-hit switch at |new_pos| = r_escape.  A crossing step that ends within the guard of a termination radius marks the lane.
@@ -878,32 +901,41 @@ struct Ray {
         if (f_new * f_new < BHR_F_GUARD * BHR_F_GUARD * r2n) sh.unsure = 1;
         bool hit_now = false;
         if (SRC == 2) {
-            if (alive) volume_segment(a, sh, to3d(u, w), to3d(nu, nw), to3d(du, dw), f_old, f_new, q_rcp(ir), r2n * q_rsq(r2n));
-        } else if (alive && f_old * f_new < 0) {
-            float t_frac = f_old / (f_old - f_new + 1e-8f);
-            float hu = fmaf(t_frac, nu - u, u), hw = fmaf(t_frac, nw - w, w);
-            float hx = fmaf(hu, g1.x, hw * g2.x);
-            float hy = fmaf(hu, g1.y, hw * g2.y);
-            float hr2 = fmaf(hx, hx, hy * hy);
-            float hit_r = hr2 * q_rsq(hr2);
-            // the annulus test is the other switch: a crossing within the guard of either edge marks the lane
-            if (fabsf(hit_r - a.r_outer) < BHR_EDGE_GUARD * a.r_outer || fabsf(hit_r - a.r_inner) < BHR_EDGE_GUARD * a.r_inner) sh.unsure = 1;
-            if (a.r_outer >= hit_r && hit_r >= a.r_inner) {   // render.py:2951
-                V3 dir3 = to3d(du, dw);                  // direction at the START of the step (render.py:2954)
-                Pending<DIFF> h;
-                h.hit_x = hx;
-                h.hit_y = hy;
-                h.to_cam = mk(-dir3.x, -dir3.y, -dir3.z);
-                if (DIFF) h.dxx = h.dxy = h.dyx = h.dyy = 0.0f;   // attached below, once the new differentials exist
-                park_store<DIFF>(n_pend, h);                      // a free slot is guaranteed (march_tile_kernel)
-                n_pend += 1;
-                hit_now = true;
+            if (alive) volume_segment(a, sh, to3d(u, w), to3d(nu, nw), to3d(du, dw), f_old, f_new, q_rcp(ij), r2n * q_rsq(r2n));
+        } else if (__builtin_amdgcn_ballot_w64(crossing) != 0ull) {
+            // (a wave-uniform branch around the crossing code: `full` is then a uniform value set under uniform control, it
+            // stays in a scalar register and the march loop tests it with a scalar compare -- the per-step
+            // v_cmp(n_pend == 2) + v_cmp(n_pend > 0) of round 3 cost four plain instructions' issue time.  The branch is on
+            // the ONE compare's mask: combined with `alive` hipcc rebuilds the mask through v_cndmask + v_cmp)
+            const float bn = fmaf(-a.tan_t, g2.y, g2.z);           // n . g2 again: Bn is not kept across the loop
+            const float fo = bn * w, fn = bn * nw;
+            if (alive && fo * fn < 0) {
+                float t_frac = fo / (fo - fn + 1e-8f);
+                float hu = fmaf(t_frac, nu - u, u), hw = fmaf(t_frac, nw - w, w);
+                float hx = fmaf(hu, g1.x, hw * g2.x);
+                float hy = fmaf(hu, g1.y, hw * g2.y);
+                float hr2 = fmaf(hx, hx, hy * hy);
+                float hit_r = hr2 * q_rsq(hr2);
+                // the annulus test is the other switch: a crossing within the guard of either edge marks the lane
+                if (fabsf(hit_r - a.r_outer) < BHR_EDGE_GUARD * a.r_outer || fabsf(hit_r - a.r_inner) < BHR_EDGE_GUARD * a.r_inner) sh.unsure = 1;
+                if (a.r_outer >= hit_r && hit_r >= a.r_inner) {   // render.py:2951
+                    V3 dir3 = to3d(du, dw);                  // direction at the START of the step (render.py:2954), x tau
+                    Pending<DIFF> h;
+                    h.hit_x = hx;
+                    h.hit_y = hy;
+                    h.to_cam = mk(-dir3.x, -dir3.y, -dir3.z);
+                    if (DIFF) h.dxx = h.dxy = h.dyx = h.dyy = 0.0f;   // attached below, once the new differentials exist
+                    park_store<DIFF>(n_pend, h);                      // a free slot is guaranteed (march_tile_kernel)
+                    n_pend += 1;
+                    hit_now = true;
+                }
             }
+            full = __builtin_amdgcn_ballot_w64(n_pend == 2) != 0ull;
         }
         if (DIFF && alive) {
             // variational RK4 at the same four stage positions (render.py:2888-2911); the hit reads the
             // NEW differentials (committed before the plane test, render.py:2928-2932)
-            float i2_1 = ir * ir;
+            float i2_1 = ij * ij;
             rk4_diff(dpx, ddx, h, hh, h6, s2u, s2w, s3u, s3w, s4u, s4w, c2, c3, c4, i2_1, i2_2, i2_3, i2_4);
             rk4_diff(dpy, ddy, h, hh, h6, s2u, s2w, s3u, s3w, s4u, s4w, c2, c3, c4, i2_1, i2_2, i2_3, i2_4);
             if (hit_now) {                               // hit parked in THIS step: attach its footprint
@@ -922,14 +954,16 @@ struct Ray {
         dw = fmaf(h6, sdw, dw);                          // direction = new_dir (render.py:2921)
         u = nu;
         w = nw;
-        ir = q_rsq(r2n);
-        float i2 = ir * ir;
-        c1 = m15L2 * (i2 * i2 * ir);
-        f_old = f_new;
+        ij = q_rsq(r2n);
+        float i2 = ij * ij;
+        c1 = -(i2 * i2 * ij);
         step_count += 1;
-        done = captured ? 1 : (escaped ? 2 : (step_count >= a.max_iter ? 3 : 0));
+        done = ended ? 2 : (step_count >= a.max_iter ? 3 : 0);      // 2 = captured or escaped: escaped() tells
         return true;     // two parking slots: a step never has to be repeated
     }
+
+    // which of the two radii (or the affine limit) ended the ray: captured = inside r_s, as the loop's own test has it
+    __device__ __forceinline__ bool escaped() const { return done == 2 && !(fmaf(u, u, w * w) < BHR_RS * BHR_RS); }
 
     // shade the oldest parked crossing (lanes that have one), the second slot moves up
     __device__ __forceinline__ void flush_one(const BhrMarchArgs &a) {
@@ -940,8 +974,8 @@ struct Ray {
             shade_hit<DIFF, SRC>(a, sh, h.hit_x, h.hit_y, h.to_cam, h.dxx, h.dxy, h.dyx, h.dyy);
         }
     }
-    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix % a.width, pix / a.width, done == 2, to3d(du, dw), sh); }
-    __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int i, int j) { write_pixel(a, i, j, done == 2, to3d(du, dw), sh); }
+    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix % a.width, pix / a.width, escaped(), to3d(du, dw), sh); }
+    __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int i, int j) { write_pixel(a, i, j, escaped(), to3d(du, dw), sh); }
 };
 #endif  // BHR_MARCH_STRICT
 
@@ -999,14 +1033,24 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
     int cnt = 0, passes = 0;
     asm volatile("" : "+v"(cnt));
     if (COSTS) asm volatile("" : "+v"(passes));
-    while (ray.done == 0) {
-        ray.step(a);
-        cnt += 1;
-        if (__ballot(ray.n_pend == 2)) {
-            ray.flush_one(a);
-            if (COSTS) passes += 1;
-        }
+    // The loop body twice per trip: the state a step leaves in fresh registers (new position, new plane function) is the
+    // next step's input where it stands -- rolled once, hipcc closed every iteration with three v_mov to bring it back to
+    // the registers the loop head expects.
+#define BHR_FAST_STEP()                                                                                                     \
+    ray.step(a);                                                                                                            \
+    cnt += 1;                                                                                                               \
+    if (ray.full) { /* wave-uniform, a scalar register (Ray::step): some live lane has filled both its parking slots */     \
+        asm volatile("" : "+v"(ray.n_pend)); /* the lanes' own n_pend > 0 test stays inside this branch */                  \
+        ray.flush_one(a);                                                                                                   \
+        ray.full = false;                                                                                                   \
+        if (COSTS) passes += 1;                                                                                             \
     }
+    while (ray.done == 0) {
+        BHR_FAST_STEP()
+        if (ray.done != 0) break;
+        BHR_FAST_STEP()
+    }
+#undef BHR_FAST_STEP
     ray.step_count = cnt;
     if (COSTS) {   // the lanes that were alive at the wave's last pass have seen them all
         int m = passes;
@@ -1088,8 +1132,17 @@ __global__ __launch_bounds__(256) void march_tile_mipstaged_kernel(BhrMarchArgs 
     march_tile_body<true, 3, false, false>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
+// The plain fast march (no differentials, texture source) as an entry of its own, so that its occupancy target can be set
+// without touching the other instantiations of the template: BHR_FAST_WAVES waves per SIMD (512 / waves registers per lane).
+#ifndef BHR_FAST_WAVES
+#define BHR_FAST_WAVES 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BHR_FAST_WAVES, BHR_FAST_WAVES))) void march_tile_plain_fast(BhrMarchArgs a) {
+    march_tile_body<false, 0, false, false>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+}
+
 template <bool DIFF, bool COSTS = false>
-__global__ __launch_bounds__(256) void march_tile_guard_kernel(BhrMarchArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIFF ? 4 : 5, DIFF ? 4 : 5))) void march_tile_guard_kernel(BhrMarchArgs a) {
     march_tile_body<DIFF, 0, true, COSTS>(a, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 #endif
@@ -1307,6 +1360,8 @@ int32_t BHR_MARCH_RESOURCES(int32_t *vgprs, int32_t *lds, int32_t diff) {
     hipFuncAttributes at;
 #if BHR_MARCH_STRICT && BHR_MARCH_ILP
     const void *f = diff ? (const void *)march_tile_aa_ilp : (const void *)march_tile_plain_ilp;
+#elif !BHR_MARCH_STRICT
+    const void *f = diff ? (const void *)march_tile_kernel<true, 0> : (const void *)march_tile_plain_fast;
 #else
     const void *f = diff ? (const void *)march_tile_kernel<true, 0> : (const void *)march_tile_kernel<false, 0>;
 #endif
@@ -1533,7 +1588,11 @@ int32_t BHR_LAUNCH_MARCH(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
             hipLaunchKernelGGL((march_tile_kernel<true, 0>), grid, block, 0, ctx->stream, a);
 #endif
         } else {
+#if !BHR_MARCH_STRICT
+            hipLaunchKernelGGL(march_tile_plain_fast, grid, block, 0, ctx->stream, a);
+#else
             hipLaunchKernelGGL((march_tile_kernel<false, 0>), grid, block, 0, ctx->stream, a);
+#endif
         }
 #endif
     } else {
