@@ -449,41 +449,21 @@ __global__ void bloom_pack_kernel(const float *__restrict__ disk, const float *_
 
 // H pass.  Work unit = (32-row block yb, segment of `seg` <= T output tiles along x); a workgroup = 6 waves = the three
 // channels of two consecutive units, sharing one copy of the weight table; grid ceil(units / 2).
-// T = 8 (the many-round launches of a whole 8k frame, which move the most bytes): the workgroup's two units INTERLEAVE their
-// tiles -- unit s takes tiles tb + s, tb + s + 2, ... of a double segment -- so both walk the same chunks at the same time
-// and the second request for a line finds it in the CU's L1 or in flight in L2 instead of going to the fabric 16 chunk-steps
-// after its neighbour did (split_stride; a wave issues 2 x 2 (seg - 1) + 2 NT loads instead of 2 (seg - 1) + 2 NT, the
-// pair fetches 4 seg + 2 NT - 2 chunks instead of 2 (2 seg + 2 NT - 2)).  The accumulation order of an output is unchanged.
-constexpr int split_stride(int T) { return T == 8 ? SPLIT_SUBS : 1; }
 template <int T>
 __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T == 8 ? 2 : 3, T == 8 ? 2 : 3))) void bloom_h_split_kernel(HSplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int S = split_stride(T);               // tile i of the wave is tile' tb + S i
-    const int ch = wave % 3, sub = wave / 3;
-    int yb, tb, te;
-    if (S == 1) {
-        const int unit = blockIdx.x * SPLIT_SUBS + sub;
-        yb = unit / a.n_seg;
-        tb = (unit - yb * a.n_seg) * a.seg;
-        te = yb < a.YB ? min(tb + a.seg, a.n_tx) : tb;
-    } else {
-        const int ng = (a.n_seg + S - 1) / S;        // double segments per row of tiles
-        yb = blockIdx.x / ng;
-        const int g = blockIdx.x - yb * ng;
-        tb = g * S * a.seg + sub;
-        te = min((g + 1) * S * a.seg, a.n_tx);
-    }
-    if (tb >= te) {                                  // no work: only the workgroup's table staging
+    const int ch = wave % 3, unit = blockIdx.x * SPLIT_SUBS + wave / 3;
+    if (unit >= a.n_seg * a.YB) {                    // no work: only the workgroup's table staging
         stage_table(lds_b, a.w16, a.table_bytes);
         __syncthreads();
         return;
     }
-    const int n = lane & 31, h = lane >> 5, NT = a.NT;
-    const int tl = tb + S * ((te - 1 - tb) / S);     // the wave's last tile'
+    const int yb = unit / a.n_seg, n = lane & 31, h = lane >> 5, NT = a.NT;
+    const int tb = (unit - yb * a.n_seg) * a.seg, te = min(tb + a.seg, a.n_tx);
     const int part_w = 8 * split_csb(NT);
-    // tile i of the wave at chunk' cp reads the window k = cp - 2 (tb + S i): one address per chunk, immediate offsets per tile
-    const unsigned char *wl = weight_base(lds_b, ch, NT, n, h) - 64 * S * (T - 1);
+    // tile i of the wave at chunk' cp reads the window k = cp - 2 (tb + i): one address per chunk, immediate offsets per tile
+    const unsigned char *wl = weight_base(lds_b, ch, NT, n, h) - 64 * (T - 1);
     const size_t part_a = (size_t)a.YB * a.GP * 256;
     const _Float16 *src = a.pa + ((((size_t)(ch * 2) * a.YB + yb) * a.GP + h) * 32 + n) * 8;      // + 512 halfs per chunk'
 
@@ -493,7 +473,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    const int c0 = 2 * tb, c1 = 2 * tl + 2 * NT - 1;
+    const int c0 = 2 * tb, c1 = 2 * (te - 1) + 2 * NT - 1;
     auto load = [&](int cp, u32x4 (&d)[2]) {
         const _Float16 *q = src + (size_t)min(cp, c1) * 512;          // prefetch past the end: a re-read
         d[0] = *reinterpret_cast<const u32x4 *>(q);
@@ -504,10 +484,10 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
         const unsigned char *wq = wl + 32 * k0;
 #pragma unroll
         for (int i = 0; i < T; ++i) {
-            const int k = k0 - 2 * S * i;
-            if (k >= 0 && k < 2 * NT && tb + S * i < te) {             // wave uniform: this chunk lies in tile i's band
-                const u32x4 wh = *reinterpret_cast<const u32x4 *>(wq + 64 * S * (T - 1 - i));
-                const u32x4 wlo = *reinterpret_cast<const u32x4 *>(wq + 64 * S * (T - 1 - i) + part_w);
+            const int k = k0 - 2 * i;
+            if (k >= 0 && k < 2 * NT && tb + i < te) {                 // wave uniform: this chunk lies in tile i's band
+                const u32x4 wh = *reinterpret_cast<const u32x4 *>(wq + 64 * (T - 1 - i));
+                const u32x4 wlo = *reinterpret_cast<const u32x4 *>(wq + 64 * (T - 1 - i) + part_w);
                 BHR_MFMA3_DATA_A(acc[i], d[0], d[1], wh, wlo);
             }
         }
@@ -538,15 +518,15 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     float wsv[T];
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-        const int x = 32 * (tb + S * i) + n;
-        wsv[i] = (tb + S * i < te && x < a.W) ? a.wsum_h[(3 + ch) * a.W + x] : 0.0f;
+        const int x = 32 * (tb + i) + n;
+        wsv[i] = (tb + i < te && x < a.W) ? a.wsum_h[(3 + ch) * a.W + x] : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < T; ++i) asm volatile("" : "+v"(wsv[i]));          // all of them HERE: no load is left to wait for between the tiles' stores
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-        if (tb + S * i >= te) continue;
-        const int x = 32 * (tb + S * i) + n;
+        if (tb + i >= te) continue;
+        const int x = 32 * (tb + i) + n;
         const float ws = wsv[i];                                           // a sum back to a scaled pixel
         unsigned int ph[4][2], pl[4][2];                                   // [quad][dword]: 4 rows x f16, hi and lo halves
 #pragma unroll
@@ -581,7 +561,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
             const bool whole = aligned8 && yq + 7 < a.rows;
             auto put = [&](_Float16 *pb, int pbr, int pend, int gr) {
                 const size_t part = (size_t)a.n_tx * gr * 256;
-                _Float16 *base = pb + ((((size_t)(ch * 2) * a.n_tx + (tb + S * i)) * gr) * 32 + n) * 8;      // + 256 halfs per group
+                _Float16 *base = pb + ((((size_t)(ch * 2) * a.n_tx + (tb + i)) * gr) * 32 + n) * 8;      // + 256 halfs per group
                 if (whole) {
                     if (gq < pbr || gq + 7 >= pend) return;
                     _Float16 *dst = base + (size_t)((gq - pbr) >> 3) * 256;
@@ -613,42 +593,17 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
         a.zero_cell[(size_t)threadIdx.x * BHR_STEP_STRIDE] = 0ull;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int S = split_stride(T);               // tile i of the wave is tile' tb + S i (see the H pass)
     const int ch = wave % 3, sub = wave / 3, n_strips = a.WP / 32;
     const int wg = blockIdx.x;
-    int strip, tb, te, n_it = 0;                     // n_it: tiles of the workgroup's longest unit (barrier rounds below)
-    bool live;
-    if (S == 1) {
-        int unit = wg * SPLIT_SUBS + sub;             // strip-major: a strip's segments are neighbours (they share 2 NT - 2 chunks)
-        live = unit < a.n_seg * n_strips;            // a unit past the end walks unit 0 and stores nothing: every wave reaches the barriers below
-        if (!live) unit = 0;
-        strip = unit / a.n_seg;
-        tb = a.seg_t0 + (unit - strip * a.n_seg) * a.seg;
-        te = min(tb + a.seg, a.seg_t1);
-#pragma unroll
-        for (int q = 0; q < SPLIT_SUBS; ++q) {
-            const int u = wg * SPLIT_SUBS + q;
-            if (u < a.n_seg * n_strips) {
-                const int b0 = a.seg_t0 + (u % a.n_seg) * a.seg;
-                n_it = max(n_it, min(b0 + a.seg, a.seg_t1) - b0);
-            }
-        }
-    } else {
-        const int ng = (a.n_seg + S - 1) / S;        // double segments per strip
-        strip = wg / ng;
-        const int g = wg - strip * ng;
-        const int gb = a.seg_t0 + g * S * a.seg;     // the double segment's first tile'
-        te = min(gb + S * a.seg, a.seg_t1);
-        tb = gb + sub;
-        live = tb < te;
-        if (!live) tb = gb;                           // (a double segment of one tile: its second unit walks the first's band and stores nothing)
-        n_it = (te - gb + S - 1) / S;                 // unit 0's tiles: the most
-    }
+    int unit = wg * SPLIT_SUBS + sub;                 // strip-major: a strip's segments are neighbours (they share 2 NT - 2 chunks)
+    const bool live = unit < a.n_seg * n_strips;     // a unit past the end walks unit 0 and stores nothing: every wave reaches the barriers below
+    if (!live) unit = 0;
+    const int strip = unit / a.n_seg, yseg = unit - strip * a.n_seg;
     const int n = lane & 31, h = lane >> 5, NT = a.NT;
     const int x = strip * 32 + n;
-    const int tl = tb + S * ((te - 1 - tb) / S);     // the wave's last tile'
+    const int tb = a.seg_t0 + yseg * a.seg, te = min(tb + a.seg, a.seg_t1);
     const int part_w = 8 * split_csb(NT);
-    const unsigned char *wl = weight_base(lds_b, ch, NT, n, h) - 64 * S * (T - 1);
+    const unsigned char *wl = weight_base(lds_b, ch, NT, n, h) - 64 * (T - 1);
     const size_t part_b = (size_t)(a.WP / 32) * a.GR * 256, chunk_b = 512;                  // halfs: the strip's groups are contiguous
     const _Float16 *src = a.pb + ((((size_t)(ch * 2) * (a.WP / 32) + strip) * a.GR + h) * 32 + n) * 8;
 
@@ -658,7 +613,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    const int c0 = 2 * tb, c1 = 2 * tl + 2 * NT - 1;
+    const int c0 = 2 * tb, c1 = 2 * (te - 1) + 2 * NT - 1;
     auto load = [&](int cp, u32x4 (&d)[2]) {
         const _Float16 *q = src + (size_t)min(cp, c1) * chunk_b;
         d[0] = *reinterpret_cast<const u32x4 *>(q);
@@ -669,10 +624,10 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
         const unsigned char *wq = wl + 32 * k0;
 #pragma unroll
         for (int i = 0; i < T; ++i) {
-            const int k = k0 - 2 * S * i;
-            if (k >= 0 && k < 2 * NT && tb + S * i < te) {
-                const u32x4 wh = *reinterpret_cast<const u32x4 *>(wq + 64 * S * (T - 1 - i));
-                const u32x4 wlo = *reinterpret_cast<const u32x4 *>(wq + 64 * S * (T - 1 - i) + part_w);
+            const int k = k0 - 2 * i;
+            if (k >= 0 && k < 2 * NT && tb + i < te) {
+                const u32x4 wh = *reinterpret_cast<const u32x4 *>(wq + 64 * (T - 1 - i));
+                const u32x4 wlo = *reinterpret_cast<const u32x4 *>(wq + 64 * (T - 1 - i) + part_w);
                 BHR_MFMA3_DATA_B(acc[i], d[0], d[1], wh, wlo);
             }
         }
@@ -703,12 +658,21 @@ __global__ __launch_bounds__(SPLIT_THREADS) __attribute__((amdgpu_waves_per_eu(T
     // all six waves `n_it` times, the longest of them; a unit works in the rounds it has a tile for.
     const bool coop = (a.W & 3) == 0;                                   // uniform over the launch
     const bool whole = (strip + 1) * 32 <= a.W;                         // this unit's strip is 32 full columns
+    int n_it = 0;
+#pragma unroll
+    for (int q = 0; q < SPLIT_SUBS; ++q) {
+        const int u = wg * SPLIT_SUBS + q;
+        if (u < a.n_seg * n_strips) {
+            const int b0 = a.seg_t0 + (u % a.n_seg) * a.seg;
+            n_it = max(n_it, min(b0 + a.seg, a.seg_t1) - b0);
+        }
+    }
     float *tile = reinterpret_cast<float *>(lds_b + a.table_bytes) + sub * (32 * 96);
 #pragma unroll
     for (int i = 0; i < T; ++i) {
         if (i >= n_it) break;
-        const bool on = live && tb + S * i < te;
-        const int yg0 = 32 * (a.t_first + tb + S * i);
+        const bool on = live && tb + i < te;
+        const int yg0 = 32 * (a.t_first + tb + i);
         if (!coop || !whole) {
             if (on && x < a.W) {
 #pragma unroll
@@ -925,8 +889,7 @@ int32_t bhr_launch_bloom_h(bhr_ctx *ctx) {
         const SplitPlan pl = plan_segments(g.n_tx, g.YB, g.NT, ctx->opt.bloom_tiles);
         a.seg = pl.seg;
         a.n_seg = pl.n_seg;
-        const int st = split_stride(pl.T);             // T = 8: one workgroup per double segment of a row of tiles
-        dim3 grid(st == 1 ? ((long long)a.n_seg * g.YB + SPLIT_SUBS - 1) / SPLIT_SUBS : (long long)((a.n_seg + st - 1) / st) * g.YB), block(SPLIT_THREADS);
+        dim3 grid(((long long)a.n_seg * g.YB + SPLIT_SUBS - 1) / SPLIT_SUBS), block(SPLIT_THREADS);
         if (pl.T == 8) { BHR_TRY(allow_lds((const void *)bloom_h_split_kernel<8>, g.table_bytes)); hipLaunchKernelGGL(bloom_h_split_kernel<8>, grid, block, g.table_bytes, ctx->stream, a); }
         else { BHR_TRY(allow_lds((const void *)bloom_h_split_kernel<5>, g.table_bytes)); hipLaunchKernelGGL(bloom_h_split_kernel<5>, grid, block, g.table_bytes, ctx->stream, a); }
         BHR_HIP(hipGetLastError());
@@ -982,8 +945,7 @@ int32_t bhr_launch_bloom_v_rows(bhr_ctx *ctx, int32_t with_bloom, int32_t r0, in
         const SplitPlan pl = plan_segments(nt, g.n_tx, g.NT, ctx->opt.bloom_tiles);
         a.seg = pl.seg;
         a.n_seg = pl.n_seg;
-        const int st = split_stride(pl.T);
-        dim3 grid(st == 1 ? ((long long)a.n_seg * g.n_tx + SPLIT_SUBS - 1) / SPLIT_SUBS : (long long)((a.n_seg + st - 1) / st) * g.n_tx), block(SPLIT_THREADS);
+        dim3 grid(((long long)a.n_seg * g.n_tx + SPLIT_SUBS - 1) / SPLIT_SUBS), block(SPLIT_THREADS);
         const size_t lds = (size_t)g.table_bytes + SPLIT_SUBS * 32 * 96 * sizeof(float);     // table + one [32][32][3] tile per strip
         if (pl.T == 8) { BHR_TRY(allow_lds((const void *)bloom_v_split_kernel<8>, lds)); hipLaunchKernelGGL(bloom_v_split_kernel<8>, grid, block, lds, ctx->stream, a); }
         else { BHR_TRY(allow_lds((const void *)bloom_v_split_kernel<5>, lds)); hipLaunchKernelGGL(bloom_v_split_kernel<5>, grid, block, lds, ctx->stream, a); }

@@ -962,6 +962,14 @@ struct Ray {
         return true;     // two parking slots: a step never has to be repeated
     }
 
+    // The loop's own termination test once more, on the state a finished lane is left with (the same expressions on the same
+    // values): the tile kernels call it behind the march loop instead of reading `done` back -- a value written inside a
+    // loop that lanes leave at different trips and read behind it costs three scalar mask instructions per trip and per
+    // bit to keep (the exit mask alone is the loop's own).
+    __device__ __forceinline__ void settle(const BhrMarchArgs &a) {
+        const float r2 = fmaf(u, u, w * w);
+        done = (__builtin_amdgcn_fmed3f(r2, BHR_RS * BHR_RS, esc2) != r2 || affine > a.max_affine_u) ? 2 : 3;
+    }
     // which of the two radii (or the affine limit) ended the ray: captured = inside r_s, as the loop's own test has it
     __device__ __forceinline__ bool escaped() const { return done == 2 && !(fmaf(u, u, w * w) < BHR_RS * BHR_RS); }
 
@@ -1052,6 +1060,8 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
     }
 #undef BHR_FAST_STEP
     ray.step_count = cnt;
+    if (cnt > 0) ray.settle(a);
+    else ray.done = 3;               // no step taken (max_iter <= 0, or no ray: those lanes store nothing)
     if (COSTS) {   // the lanes that were alive at the wave's last pass have seen them all
         int m = passes;
 #pragma unroll
