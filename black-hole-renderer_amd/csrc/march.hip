@@ -551,7 +551,8 @@ struct Ray {
     int n_pend;    // parked disk crossings (0..2), in the lane's LDS slots, oldest first
     int step_count;
     int pix;       // linear pixel index inside the row block, -1 = lane has no ray
-    int done;      // 0 running, 1 captured, 2 escaped, 3 ran out of iterations, 4 empty lane
+    int done;      // 0 running, 2 captured or escaped (escaped() tells), 3 ran out of iterations, 4 empty lane
+    bool full;     // wave-uniform: some live lane has both its parking slots occupied
     V3 dpx, ddx, dpy, ddy;   // ray differentials (DIFF only)
 
     __device__ __forceinline__ void init(const BhrMarchArgs &a, int i, int j_local) {
@@ -569,6 +570,7 @@ struct Ray {
         sh.alpha_total = 0.0f;
         sh.unsure = 0;
         n_pend = 0;
+        full = false;
         step_count = 0;
         done = a.max_iter <= 0 ? 3 : 0;
         pix = j_local * a.width + i;
@@ -659,29 +661,36 @@ struct Ray {
         float r2n = dot(np, np);
         float rn = sqrt_rn(r2n);
         float aff = affine + h;
-        // termination precedes the plane test (render.py:2916-2926)
-        const bool captured = rn < BHR_RS;
-        const bool escaped = !captured && (rn > a.r_esc || aff > a.max_affine);
-        const bool alive = !captured && !escaped;
+        // termination precedes the plane test (render.py:2916-2926): the ray goes on iff r_s <= |new_pos| <= r_escape and the
+        // affine parameter is within its limit -- the reference's strict inequalities, the two radii as one v_med3 + one
+        // compare (which of them ended the ray: escaped(), behind the loop)
+        const bool ended = __builtin_amdgcn_fmed3f(rn, BHR_RS, a.r_esc) != rn || aff > a.max_affine;
+        const bool alive = !ended;
         float f_new = np.z - np.y * a.tan_t;
+        const bool crossing = f_old * f_new < 0;
         if (SRC == 2) {
             if (alive) volume_segment(a, sh, p, np, d, f_old, f_new, r, rn);
-        } else if (alive && f_old * f_new < 0) {
-            float t_frac = div_rn(f_old, f_old - f_new + 1e-8f);
-            float hx = p.x + t_frac * (np.x - p.x);
-            float hy = p.y + t_frac * (np.y - p.y);
-            float hit_r = sqrt_rn(hx * hx + hy * hy);
-            if (a.r_outer >= hit_r && hit_r >= a.r_inner) {   // render.py:2951
-                Pending<DIFF> h;
-                h.hit_x = hx;
-                h.hit_y = hy;
-                h.to_cam = mk(-d.x, -d.y, -d.z);              // direction at the START of the step (render.py:2954)
-                // the differentials were committed BEFORE the hit interpolation (render.py:2928-2932),
-                // hence hit_d_pos == new_d_pos in render.py:2947-2949
-                if (DIFF) { h.dxx = ndpx.x; h.dxy = ndpx.y; h.dyx = ndpy.x; h.dyy = ndpy.y; }
-                park_store<DIFF>(n_pend, h);                  // a free slot is guaranteed (march_tile_body flushes at 2)
-                n_pend += 1;
+        } else if (__builtin_amdgcn_ballot_w64(crossing) != 0ull) {
+            // a wave-uniform branch around the crossing code (a few steps per ray): `full` is a uniform value set under uniform
+            // control and lives in a scalar register -- the march loop tests it instead of comparing n_pend in every step
+            if (alive && crossing) {
+                float t_frac = div_rn(f_old, f_old - f_new + 1e-8f);
+                float hx = p.x + t_frac * (np.x - p.x);
+                float hy = p.y + t_frac * (np.y - p.y);
+                float hit_r = sqrt_rn(hx * hx + hy * hy);
+                if (a.r_outer >= hit_r && hit_r >= a.r_inner) {   // render.py:2951
+                    Pending<DIFF> h;
+                    h.hit_x = hx;
+                    h.hit_y = hy;
+                    h.to_cam = mk(-d.x, -d.y, -d.z);              // direction at the START of the step (render.py:2954)
+                    // the differentials were committed BEFORE the hit interpolation (render.py:2928-2932),
+                    // hence hit_d_pos == new_d_pos in render.py:2947-2949
+                    if (DIFF) { h.dxx = ndpx.x; h.dxy = ndpx.y; h.dyx = ndpy.x; h.dyy = ndpy.y; }
+                    park_store<DIFF>(n_pend, h);                  // a free slot is guaranteed (march_tile_body flushes at 2)
+                    n_pend += 1;
+                }
             }
+            full = __builtin_amdgcn_ballot_w64(n_pend == 2) != 0ull;
         }
         affine = aff;
         if (DIFF) { dpx = ndpx; ddx = nddx; dpy = ndpy; ddy = nddy; }
@@ -691,9 +700,17 @@ struct Ray {
         r2p = r2n;
         f_old = f_new;
         step_count += 1;
-        done = captured ? 1 : (escaped ? 2 : (step_count >= a.max_iter ? 3 : 0));
+        done = ended ? 2 : (step_count >= a.max_iter ? 3 : 0);
         return true;
     }
+
+    // The loop's own termination test once more, on the state a finished lane is left with (r = |p| and the affine parameter
+    // are those very values): the tile kernels call it behind the march loop instead of reading `done` back (see the fast
+    // Ray's settle()).
+    __device__ __forceinline__ void settle(const BhrMarchArgs &a) {
+        done = (__builtin_amdgcn_fmed3f(r, BHR_RS, a.r_esc) != r || affine > a.max_affine) ? 2 : 3;
+    }
+    __device__ __forceinline__ bool escaped() const { return done == 2 && !(r < BHR_RS); }
 
     // shade the oldest parked crossing (lanes that have one), the second slot moves up
     __device__ __forceinline__ void flush_one(const BhrMarchArgs &a) {
@@ -704,8 +721,8 @@ struct Ray {
             shade_hit<DIFF, SRC>(a, sh, h.hit_x, h.hit_y, h.to_cam, h.dxx, h.dxy, h.dyx, h.dyy);
         }
     }
-    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix % a.width, pix / a.width, done == 2, d, sh); }
-    __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int i, int j) { write_pixel(a, i, j, done == 2, d, sh); }
+    __device__ __forceinline__ void finish(const BhrMarchArgs &a) { write_pixel(a, pix % a.width, pix / a.width, escaped(), d, sh); }
+    __device__ __forceinline__ void finish_at(const BhrMarchArgs &a, int i, int j) { write_pixel(a, i, j, escaped(), d, sh); }
 };
 
 #else
@@ -1031,8 +1048,7 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
     // empty (the hardware form of "loop while __ballot(alive)").  Written without an inner `if` because
     // hipcc otherwise shuttles the whole ray state through v_mov at every iteration (24 moves/step).
     unsigned int flushes = 0;     // wave-uniform
-#if !BHR_MARCH_STRICT
-    // Fast build: values that are uniform over the live lanes but read behind the divergent loop (the step count, the
+    // Values that are uniform over the live lanes but read behind the divergent loop (the step count, the
     // number of shading passes) are kept in scalar registers by hipcc and copied into a vector register in EVERY
     // iteration for the lanes that leave (v_mov from an SGPR: 4 issue cycles each).  The lane's own count in a vector
     // register costs one plain v_add.  The shading passes inside the loop are counted only by the instantiations that
@@ -1068,13 +1084,6 @@ __device__ __forceinline__ void march_tile_body(const BhrMarchArgs &a, const int
         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, BHR_WAVE));
         flushes = (unsigned int)m;
     }
-#else
-    while (ray.done == 0) {
-        ray.step(a);
-        // some live lane has filled both its parking slots: every live lane shades its older crossing
-        if (__ballot(ray.n_pend == 2)) { ray.flush_one(a); flushes += 1u; }
-    }
-#endif
     if (__ballot(ray.n_pend > 0)) { ray.flush_one(a); flushes += 1u; }
     if (__ballot(ray.n_pend > 0)) { ray.flush_one(a); flushes += 1u; }
     {
@@ -1176,7 +1185,7 @@ __global__ __launch_bounds__(256) void march_fix_kernel(BhrMarchArgs a) {
     if (!valid) ray.done = 4;
     while (ray.done == 0) {
         ray.step(a);
-        if (__ballot(ray.n_pend == 2)) ray.flush_one(a);
+        if (ray.full) { ray.flush_one(a); ray.full = false; }
     }
     if (__ballot(ray.n_pend > 0)) ray.flush_one(a);
     if (__ballot(ray.n_pend > 0)) ray.flush_one(a);

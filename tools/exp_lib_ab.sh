@@ -7,6 +7,6 @@ for r in $(seq $ROUNDS); do for lib in "$@"; do
   python - "$lib" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json"))
-print(sys.argv[1], "| fps", round(d["fps"], 1), "march_ms", round(d["kernel_ms"]["march"], 4), "post_ms", round(d["kernel_ms"]["bloom_and_combine"], 4), "vgprs", d["kernel_ms"].get("march_vgprs"), flush=True)
+print(sys.argv[1], "| fps", round(d["fps"], 1), "march_ms", round(d["kernel_ms"]["march"], 4), "post_ms", round(d["kernel_ms"]["bloom_and_combine"], 4), "vgprs", d["kernel_ms"].get("march_vgprs"), "calib", d.get("stream_calibration", {}).get("kept"), d.get("stream_calibration", {}).get("candidates_fps"), "share", d.get("stream_map"), flush=True)
 PY
 done; done
