@@ -828,12 +828,23 @@ struct Ray {
         }
     }
 
-    // coefficient c(s) = -1 / r^5 and 1/r^2 at the in-plane point (su, sw)
-    __device__ __forceinline__ float coef(float su, float sw, float &i2) const {
-        float r2 = fmaf(su, su, sw * sw);
-        float i1 = q_rsq(r2);
+    // coefficient c = -1 / r^5 and 1/r^2 from i1 = 1/r
+    __device__ __forceinline__ float coef(float i1, float &i2) const {
         i2 = i1 * i1;
         return -(i2 * i2 * i1);
+    }
+    // Two independent v_rsq back to back.  A transcendental costs 8 issue cycles behind another one and ~12.7 behind a
+    // plain instruction (the stream changes pipes): the radii of stages 2 and 3 are both known before either
+    // coefficient is needed, and so are stage 4's and the new position's -- five transcendentals per step in three groups
+    // instead of five.  (s_nop: a transcendental's result needs one wait state before a VALU reads it; hipcc adds it behind
+    // its own v_rsq, not behind an asm.)
+    static __device__ __forceinline__ void rsq_pair(float x, float y, float &a, float &b) {
+#ifdef BHR_NO_RSQ_PAIR
+        a = q_rsq(x);
+        b = q_rsq(y);
+#else
+        asm("v_rsq_f32 %0, %2\n\tv_rsq_f32 %1, %3\n\ts_nop 0" : "=&v"(a), "=&v"(b) : "v"(x), "v"(y));
+#endif
     }
     // J(s) delta with delta = (in-plane u, in-plane w, out-of-plane n)
     __device__ __forceinline__ V3 jac(float su, float sw, V3 dl, float c, float i2) const {
@@ -879,21 +890,24 @@ struct Ray {
         float s2u = fmaf(hh, du, u), s2w = fmaf(hh, dw, w);
         float v2u = fmaf(hh, a1u, du), v2w = fmaf(hh, a1w, dw);
         float i2_2, i2_3, i2_4;
-        float c2 = coef(s2u, s2w, i2_2);
-        float a2u = c2 * s2u, a2w = c2 * s2w;
         float s3u = fmaf(hh, v2u, u), s3w = fmaf(hh, v2w, w);
+        float i1_2, i1_3, i1_4, i1_n;
+        rsq_pair(fmaf(s2u, s2u, s2w * s2w), fmaf(s3u, s3u, s3w * s3w), i1_2, i1_3);
+        float c2 = coef(i1_2, i2_2);
+        float a2u = c2 * s2u, a2w = c2 * s2w;
         float v3u = fmaf(hh, a2u, du), v3w = fmaf(hh, a2w, dw);
-        float c3 = coef(s3u, s3w, i2_3);
+        float c3 = coef(i1_3, i2_3);
         float a3u = c3 * s3u, a3w = c3 * s3w;
         float s4u = fmaf(h, v3u, u), s4w = fmaf(h, v3w, w);
         float v4u = fmaf(h, a3u, du), v4w = fmaf(h, a3w, dw);
-        float c4 = coef(s4u, s4w, i2_4);
         float nu = fmaf(h6, (du + v4u) + 2.0f * (v2u + v3u), u);
         float nw = fmaf(h6, (dw + v4w) + 2.0f * (v2w + v3w), w);
+        float r2n = fmaf(nu, nu, nw * nw);
+        rsq_pair(fmaf(s4u, s4u, s4w * s4w), r2n, i1_4, i1_n);
+        float c4 = coef(i1_4, i2_4);
         float sdu = fmaf(c4, s4u, a1u) + 2.0f * (a2u + a3u);
         float sdw = fmaf(c4, s4w, a1w) + 2.0f * (a2w + a3w);
 
-        float r2n = fmaf(nu, nu, nw * nw);
         // the affine parameter is kept in units of h_base: one plain v_add per step, compared against max_affine / h_base
         float aff = affine + dt_fac;
         // termination precedes the plane test (render.py:2916-2926); r < r_s  <=>  r^2 < r_s^2 etc.  One v_med3 and one
@@ -971,7 +985,7 @@ struct Ray {
         dw = fmaf(h6, sdw, dw);                          // direction = new_dir (render.py:2921)
         u = nu;
         w = nw;
-        ij = q_rsq(r2n);
+        ij = i1_n;
         float i2 = ij * ij;
         c1 = -(i2 * i2 * ij);
         step_count += 1;
