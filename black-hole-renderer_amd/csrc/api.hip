@@ -805,9 +805,17 @@ static int32_t calibrate_slot_streams(bhr_ctx *ctx, const bhr_camera *cam, uint3
     for (; n_cand < NC; ++n_cand)
         if (hipStreamCreateWithFlags(&cand[n_cand], hipStreamNonBlocking) != hipSuccess) break;
     for (int c = 0; c < NC; ++c) best_ms[c] = 1e30;
+    // Between turns everything is waited for and the timing ring is put back where the caller's frames had brought it: a turn
+    // runs at most 64 frames through the cells in front of the caller's, never round the ring into the ones his own frames are
+    // on record in (with the ring left to run, three turns of six candidates are 628 frames of a ring of 512).  The next
+    // frames' counter cells are cleared as the V pass of their predecessors would have left them.
     auto drain = [&]() -> int32_t {
         for (int k = 0; k < 2; ++k) BHR_HIP(hipStreamSynchronize(ctx->slots[k].stream));
+        for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q)
+            BHR_HIP(hipMemsetAsync(ctx->d_steps_ring + (size_t)((head0 + q) % BHR_TIMING_RING) * BHR_STEP_CELL, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->scene_stream));
         BHR_HIP(hipStreamSynchronize(ctx->scene_stream));
+        ctx->ring_head = head0;
+        ctx->next_slot = slot0;
         return BHR_OK;
     };
     auto frames = [&](int n) -> int32_t {
@@ -862,12 +870,7 @@ static int32_t calibrate_slot_streams(bhr_ctx *ctx, const bhr_camera *cam, uint3
         if (c != best && cand[c]) ctx->calib_idle[ctx->n_calib_idle++] = cand[c];
     ctx->calib_choice = best;
     for (int c = 0; c < 8; ++c) ctx->calib_fps[c] = c < n_cand && best_ms[c] < 1e29 ? (int32_t)(FRAMES * 1e3 / best_ms[c]) : 0;
-    // the timing ring goes on where the caller's frames had brought it: the turns above ran through it (same view, same
-    // ray-step counts; their event times stand in for the few frames before them), the next frames' counter cells are cleared
-    // as the V pass of their predecessors would have left them
-    for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q)
-        (void)hipMemsetAsync(ctx->d_steps_ring + (size_t)((head0 + q) % BHR_TIMING_RING) * BHR_STEP_CELL, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->scene_stream);
-    (void)hipStreamSynchronize(ctx->scene_stream);
+    // (the last drain() has left the timing ring where the caller's frames had brought it)
     ctx->ring_head = head0;
     ctx->next_slot = slot0;
     ctx->calibrating = 0;

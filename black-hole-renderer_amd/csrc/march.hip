@@ -127,6 +127,30 @@ __device__ __forceinline__ float div_rn(float a, float b) {
     float q = a * y;
     return fmaf(fmaf(-b, q, a), y, q);
 }
+// The same sequences from a seed the caller already holds: the march issues the hardware approximations of independent
+// operands back to back (a transcendental costs 8 issue cycles behind another one and ~12.7 behind a plain instruction --
+// the stream changes pipes), then refines each.  Same operations on the same values as sqrt_rn / rcp_rn / div_rn.
+__device__ __forceinline__ float sqrt_rn_s(float x, float y) {
+    float s = x * y;
+    float r = fmaf(-s, s, x);
+    return fmaf(r, 0.5f * y, s);
+}
+__device__ __forceinline__ float rcp_rn_s(float b, float y) { return fmaf(fmaf(-b, y, 1.0f), y, y); }
+__device__ __forceinline__ float div_rn_s(float a, float b, float y0) {
+    float y = rcp_rn_s(b, y0);
+    float q = a * y;
+    return fmaf(fmaf(-b, q, a), y, q);
+}
+// (s_nop: a transcendental's result needs one wait state before a VALU reads it; hipcc adds it behind its own, not behind an asm)
+__device__ __forceinline__ void rsq2(float x, float y, float &a, float &b) {
+    asm("v_rsq_f32 %0, %2\n\tv_rsq_f32 %1, %3\n\ts_nop 0" : "=&v"(a), "=&v"(b) : "v"(x), "v"(y));
+}
+__device__ __forceinline__ void rcp2(float x, float y, float &a, float &b) {
+    asm("v_rcp_f32 %0, %2\n\tv_rcp_f32 %1, %3\n\ts_nop 0" : "=&v"(a), "=&v"(b) : "v"(x), "v"(y));
+}
+__device__ __forceinline__ void rsq_rcp_rcp(float x, float y, float &rs, float &rx, float &ry) {   // rsq(x), rcp(x), rcp(y)
+    asm("v_rsq_f32 %0, %3\n\tv_rcp_f32 %1, %3\n\tv_rcp_f32 %2, %4\n\ts_nop 0" : "=&v"(rs), "=&v"(rx), "=&v"(ry) : "v"(x), "v"(y));
+}
 // x + 0.5 y and x + 2 y: the products are exact, so one FMA rounds exactly like mul-then-add
 __device__ __forceinline__ V3 add_half(V3 x, V3 y) { return mk(fmaf(0.5f, y.x, x.x), fmaf(0.5f, y.y, x.y), fmaf(0.5f, y.z, x.z)); }
 
@@ -603,31 +627,45 @@ struct Ray {
         // canonicalising v_max, and compare + select pairs
         float r_safe;                                    // max(r, r_cap + 1e-3) without the canonicalising second v_max
         asm("v_max_f32 %0, %1, %2" : "=v"(r_safe) : "v"(r), "v"(BHR_RS + 1e-3f));
-        float far_scale = __builtin_fminf(sqrt_rn(r_safe), 10.0f);   // sqrt(r_safe / r_cap), r_cap = 1; capped at max_fac
-        float q = rcp_rn(r_safe);                        // r_cap / r_safe, r_cap = 1
+        // The eleven hardware approximations of a step (five v_rsq for the exact square roots, six v_rcp for the exact
+        // quotients) in six groups of independent operands, back to back (round 4; sqrt_rn_s / div_rn_s: the same
+        // refinements on the same seeds, every value bit for bit what the one-at-a-time order gives).
+        const float den1 = r2p * r2p * r;                // r^5 of coef(r2p, r)
+        float y_s, y_q, y_1;
+        rsq_rcp_rcp(r_safe, den1, y_s, y_q, y_1);
+        float far_scale = __builtin_fminf(sqrt_rn_s(r_safe, y_s), 10.0f);   // sqrt(r_safe / r_cap), r_cap = 1; capped at max_fac
+        float q = rcp_rn_s(r_safe, y_q);                 // r_cap / r_safe, r_cap = 1
         float near_damp = rcp_rn(fmaf(2.0f, q * q * q, 1.0f));   // 2 x is exact: one rounding, as 1 + 2 x has
         float dt_fac = __builtin_amdgcn_fmed3f(far_scale * near_damp, 0.2f, 10.0f);   // render.py:2865-2868
         float h = a.h_base * dt_fac;
 
-        float f1 = coef(r2p, r);
+        float f1 = div_rn_s(m15L2, den1, y_1);
         V3 k1p = h * d;
         V3 k1d = h * (f1 * p);
         V3 s2 = add_half(p, k1p);
         float r2_2 = dot(s2, s2);
-        float f2 = coef(r2_2, sqrt_rn(r2_2));
         V3 k2p = h * add_half(d, k1d);
-        V3 k2d = h * (f2 * s2);
         V3 s3 = add_half(p, k2p);
         float r2_3 = dot(s3, s3);
-        float f3 = coef(r2_3, sqrt_rn(r2_3));
+        float y_2, y_3;
+        rsq2(r2_2, r2_3, y_2, y_3);
+        const float den2 = r2_2 * r2_2 * sqrt_rn_s(r2_2, y_2), den3 = r2_3 * r2_3 * sqrt_rn_s(r2_3, y_3);
+        rcp2(den2, den3, y_2, y_3);
+        float f2 = div_rn_s(m15L2, den2, y_2);
+        float f3 = div_rn_s(m15L2, den3, y_3);
+        V3 k2d = h * (f2 * s2);
         V3 k3p = h * add_half(d, k2d);
         V3 k3d = h * (f3 * s3);
         V3 s4 = p + k3p;
         float r2_4 = dot(s4, s4);
-        float f4 = coef(r2_4, sqrt_rn(r2_4));
         V3 k4p = h * (d + k3d);
-        V3 k4d = h * (f4 * s4);
         V3 np = p + rk_sum(k1p, k2p, k3p, k4p);
+        float r2n = dot(np, np);
+        float y_4, y_n;
+        rsq2(r2_4, r2n, y_4, y_n);
+        float f4 = coef(r2_4, sqrt_rn_s(r2_4, y_4));
+        float rn = sqrt_rn_s(r2n, y_n);
+        V3 k4d = h * (f4 * s4);
         V3 nd = d + rk_sum(k1d, k2d, k3d, k4d);
 
         V3 ndpx, nddx, ndpy, nddy;
@@ -658,8 +696,6 @@ struct Ray {
             }
         }
 
-        float r2n = dot(np, np);
-        float rn = sqrt_rn(r2n);
         float aff = affine + h;
         // termination precedes the plane test (render.py:2916-2926): the ray goes on iff r_s <= |new_pos| <= r_escape and the
         // affine parameter is within its limit -- the reference's strict inequalities, the two radii as one v_med3 + one
