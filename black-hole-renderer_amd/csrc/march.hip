@@ -842,11 +842,7 @@ struct Ray {
         ij = 1.0f / a.r0;
         float i2 = ij * ij;
         c1 = -(i2 * i2 * ij);
-#ifdef BHR_ESC2_SGPR
-        esc2 = a.r_esc2;
-#else
         asm volatile("v_mov_b32 %0, %1" : "=v"(esc2) : "s"(a.r_esc2));
-#endif
         full = false;
         affine = 0.0f;
         sh.accum = mk(0, 0, 0);
@@ -869,19 +865,8 @@ struct Ray {
         i2 = i1 * i1;
         return -(i2 * i2 * i1);
     }
-    // Two independent v_rsq back to back.  A transcendental costs 8 issue cycles behind another one and ~12.7 behind a
-    // plain instruction (the stream changes pipes): the radii of stages 2 and 3 are both known before either
-    // coefficient is needed, and so are stage 4's and the new position's -- five transcendentals per step in three groups
-    // instead of five.  (s_nop: a transcendental's result needs one wait state before a VALU reads it; hipcc adds it behind
-    // its own v_rsq, not behind an asm.)
-    static __device__ __forceinline__ void rsq_pair(float x, float y, float &a, float &b) {
-#ifdef BHR_NO_RSQ_PAIR
-        a = q_rsq(x);
-        b = q_rsq(y);
-#else
-        asm("v_rsq_f32 %0, %2\n\tv_rsq_f32 %1, %3\n\ts_nop 0" : "=&v"(a), "=&v"(b) : "v"(x), "v"(y));
-#endif
-    }
+    // (The radii of stages 2 and 3 are both known before either coefficient is needed, and so are stage 4's and the new
+    // position's: their v_rsq go back to back -- rsq2 -- five transcendentals per step in three groups instead of five.)
     // J(s) delta with delta = (in-plane u, in-plane w, out-of-plane n)
     __device__ __forceinline__ V3 jac(float su, float sw, V3 dl, float c, float i2) const {
         float proj5 = 5.0f * fmaf(su, dl.x, sw * dl.y) * i2;
@@ -928,7 +913,7 @@ struct Ray {
         float i2_2, i2_3, i2_4;
         float s3u = fmaf(hh, v2u, u), s3w = fmaf(hh, v2w, w);
         float i1_2, i1_3, i1_4, i1_n;
-        rsq_pair(fmaf(s2u, s2u, s2w * s2w), fmaf(s3u, s3u, s3w * s3w), i1_2, i1_3);
+        rsq2(fmaf(s2u, s2u, s2w * s2w), fmaf(s3u, s3u, s3w * s3w), i1_2, i1_3);
         float c2 = coef(i1_2, i2_2);
         float a2u = c2 * s2u, a2w = c2 * s2w;
         float v3u = fmaf(hh, a2u, du), v3w = fmaf(hh, a2w, dw);
@@ -939,7 +924,7 @@ struct Ray {
         float nu = fmaf(h6, (du + v4u) + 2.0f * (v2u + v3u), u);
         float nw = fmaf(h6, (dw + v4w) + 2.0f * (v2w + v3w), w);
         float r2n = fmaf(nu, nu, nw * nw);
-        rsq_pair(fmaf(s4u, s4u, s4w * s4w), r2n, i1_4, i1_n);
+        rsq2(fmaf(s4u, s4u, s4w * s4w), r2n, i1_4, i1_n);
         float c4 = coef(i1_4, i2_4);
         float sdu = fmaf(c4, s4u, a1u) + 2.0f * (a2u + a3u);
         float sdw = fmaf(c4, s4w, a1w) + 2.0f * (a2w + a3w);
