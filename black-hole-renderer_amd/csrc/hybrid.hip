@@ -70,7 +70,7 @@ struct Hybrid {
     int32_t n_tiles_alloc;
 };
 
-void view_key(const bhr_camera *cam, double lo, double hi, double tilt_deg, double key[12]) {
+void view_key(const bhr_camera *cam, double lo, double hi, double pad, double tilt_deg, double key[12]) {
     double p[3], r2 = 0, pf = 0, pr = 0, pu = 0;
     for (int k = 0; k < 3; ++k) {
         p[k] = cam->pos[k];
@@ -80,7 +80,7 @@ void view_key(const bhr_camera *cam, double lo, double hi, double tilt_deg, doub
         pu += p[k] * (double)cam->up[k];
     }
     key[0] = sqrt(r2); key[1] = pf; key[2] = pr; key[3] = pu;
-    key[4] = cam->pixel_width; key[5] = cam->pixel_height; key[6] = lo; key[7] = hi;
+    key[4] = cam->pixel_width; key[5] = cam->pixel_height; key[6] = lo; key[7] = hi + 16.0 * pad;      // (the padding factor rides on the band's upper width: a key, not a quantity)
     // the in-plane family (classify) only exists for a camera within PLANE_SIN of the disk plane as seen from the hole: the
     // view's orientation against the disk normal enters the key there and nowhere else (an orbit about a tilted disk keeps
     // its cached lists for all the frames in which it is clear of the plane)
@@ -108,7 +108,7 @@ bool same_view(const double a[12], const double b[12]) {
 }
 
 // strict[t] = 1 for the tiles of this row block whose rays may have b in [b_c - lo, b_c + hi]
-void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, std::vector<uint8_t> &strict) {
+void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, double pad_f, std::vector<uint8_t> &strict) {
     const int W = ctx->cfg.width, H = ctx->cfg.height, row0 = ctx->cfg.row0, rows = ctx->rows;
     const int tiles_x = (W + 7) / 8, tiles_y = (rows + 7) / 8;
     double cp[3], cr[3], cu[3], cf[3], tl[3];
@@ -191,8 +191,8 @@ void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, s
             }
             if (far_cam && outgoing[g] && outgoing[g + 1] && outgoing[g + gx_n] && outgoing[g + gx_n + 1]) continue;
             // b grows with the distance from the hole's image in a convex sense (the field of view stays under 180 degrees): its
-            // maximum over the tile is at a corner, its minimum may lie on an edge -- pad by the tile's own span
-            const double pad = (double)(bmax - bmin) + 1e-3;
+            // maximum over the tile is at a corner, its minimum may lie on an edge -- pad by (a share of) the tile's own span
+            const double pad = pad_f * (double)(bmax - bmin) + 1e-3;
             if (bmax + pad >= B_CRIT - lo && bmin - pad <= B_CRIT + hi) strict[(size_t)ty * tiles_x + tx] = 1;
         }
 }
@@ -207,7 +207,7 @@ void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, s
 // waits for the strict count alone (it sizes the two march launches): ~40 us per view change whatever the resolution.
 struct ClassifyArgs {
     double cp[3], cr[3], cu[3], tl[3], nrm[3];
-    double pw, ph, r0sq, cpn, lo, hi;
+    double pw, ph, r0sq, cpn, lo, hi, pad_f;
     int32_t W, rows, row0, tiles_x, tiles_y, far_cam;
 };
 
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(CLS_EDGE * CLS_EDGE) void hybrid_classify_kernel(Cl
         if (fabs(a.cpn) < PLANE_SIN * (double)blmax && ((ups != 0 && ups != 4) || (double)smin < 1.5 * PLANE_SIN)) f = 1;
         else if (a.far_cam && outs == 4) f = 0;
         else {
-            const double pad = (double)(bmax - bmin) + 1e-3;
+            const double pad = a.pad_f * (double)(bmax - bmin) + 1e-3;
             f = (bmax + pad >= B_CRIT - a.lo && bmin - pad <= B_CRIT + a.hi) ? 1 : 0;
         }
         flags[(size_t)ty * a.tiles_x + tx] = (uint8_t)f;
@@ -438,7 +438,8 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
     const double lo = h->lo * widen, hi = h->hi * widen;
     h->eff_lo = lo;
     h->eff_hi = hi;
-    view_key(cam, lo, hi, (double)ctx->cfg.disk_tilt_deg, key);
+    const double pad_f = ctx->opt.hybrid_pad;
+    view_key(cam, lo, hi, pad_f, (double)ctx->cfg.disk_tilt_deg, key);
     const int n_tiles = ctx->tile_order_n;
     const bool on_device = ctx->opt.hybrid_classify != 0;
     SlotLists &s = h->slot[ctx->active_slot >= 0 && ctx->active_slot < BHR_MAX_FRAME_SLOTS ? ctx->active_slot : 0][id];
@@ -485,7 +486,7 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
                 const double tilt = (double)ctx->cfg.disk_tilt_deg * 3.14159265358979323846 / 180.0;
                 ca.nrm[0] = 0.0; ca.nrm[1] = -sin(tilt); ca.nrm[2] = cos(tilt);
                 ca.cpn = ca.cp[0] * ca.nrm[0] + ca.cp[1] * ca.nrm[1] + ca.cp[2] * ca.nrm[2];
-                ca.lo = lo; ca.hi = hi;
+                ca.lo = lo; ca.hi = hi; ca.pad_f = pad_f;
                 ca.W = W; ca.rows = ctx->rows; ca.row0 = ctx->cfg.row0;
                 ca.tiles_x = (W + 7) / 8; ca.tiles_y = (ctx->rows + 7) / 8;
                 ca.far_cam = ca.r0sq > 9.0;
@@ -521,7 +522,7 @@ int32_t bhr_launch_march_hybrid(bhr_ctx *ctx, const bhr_camera *cam, uint32_t fl
         }
     } else {
         if (new_view) {
-            classify(ctx, cam, lo, hi, h->strict);
+            classify(ctx, cam, lo, hi, pad_f, h->strict);
             int n = 0;
             for (int k = 0; k < ctx->tile_order_n; ++k) n += h->strict[(size_t)k];
             h->n_strict = n;
