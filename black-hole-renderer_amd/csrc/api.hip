@@ -116,10 +116,7 @@ static void read_options(bhr_options *o) {
         double lo = 0, hi = 0;
         if (sscanf(e, "%lf,%lf", &lo, &hi) == 2 && lo >= 0 && hi >= 0) { o->hybrid_band[0] = lo; o->hybrid_band[1] = hi; o->hybrid_band_set = 1; }
     }
-    // share of a tile's own span of b it is padded by in the strict-band test.  Round 3 padded by the whole span (the minimum of
-    // b over a tile may lie on an edge, not at a corner: a sagitta of 2 % of the span at 192 x 128, 0.2 % at fhd); half of it
-    // leaves the fhd bench frame and 23 fuzzed fhd views where they were (RMSE against strict unchanged to 1e-7, the same pixels
-    // beyond 1e-3) with 12 % fewer strict tiles (2216 -> 1942: march 0.344 -> 0.334 ms on one box; tools/exp_hybrid_pad.py)
+    // share of its own span of b a SMALL tile is padded by in the strict-band test (hybrid.hip: tile_pad; tools/exp_hybrid_pad.py)
     o->hybrid_pad = 0.5;
     if (const char *e = getenv("BHR_HYBRID_PAD")) { const double v = atof(e); if (v >= 0.0 && v <= 4.0) o->hybrid_pad = v; }
     o->hybrid_streams = num("BHR_HYBRID_STREAMS", -1);

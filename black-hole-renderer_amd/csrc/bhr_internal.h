@@ -126,7 +126,7 @@ struct bhr_options {
     int32_t hybrid_repair;      // BHR_HYBRID_REPAIR: -1 by view (default), 0 / 1 guards + strict fix list off / on
     double hybrid_band[2];      // BHR_HYBRID_BAND="lo,hi": strict band around b_c in r_s (default 0.085, 0.36)
     int32_t hybrid_band_set;
-    double hybrid_pad;          // share of a tile's own span of b it is padded by in the strict-band test (BHR_HYBRID_PAD, default 0.5)
+    double hybrid_pad;          // share of its own span of b a small tile is padded by in the strict-band test (BHR_HYBRID_PAD, default 0.5; hybrid.hip: tile_pad)
     int32_t hybrid_streams;     // BHR_HYBRID_STREAMS: 1 both lists of a hybrid march on one stream, 2 on two, -1 (default) 1 where two frame slots overlap frames, else 2
     int32_t calibrate_streams;  // BHR_CALIBRATE_STREAMS: 1 (default) a two-slot context picks slot 1's stream by timing candidates (api.hip)
     int32_t hybrid_swap;        // BHR_HYBRID_SWAP: 1 (default) the fast list on the frame's stream and the strict one on the second, 0 the other way round

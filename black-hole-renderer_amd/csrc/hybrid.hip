@@ -107,6 +107,17 @@ bool same_view(const double a[12], const double b[12]) {
     return true;
 }
 
+// Padding of a tile's range of b in the band test.  A tile whose span is a large part of the band (low resolutions, far cameras:
+// >= 0.2 r_s against a band of 0.445) is padded by its whole span, as in round 3 -- halving it there raised the share of fuzzed
+// 192 x 128 views beyond 6e-5 from 1.3 to 1.8 % (`profiles/r04d_fuzz_hybrid_*`); one whose span is <= 0.1 r_s (the ring tiles of
+// an fhd frame from 6 r_s: 0.08) by the share pad_f of it (option hybrid_pad, default 0.5: the sagitta that the padding is for
+// is 0.2 % of the span there), linearly in between.
+__host__ __device__ inline double tile_pad(double span, double pad_f) {
+#pragma clang fp contract(off)
+    const double t = span <= 0.1 ? 0.0 : (span >= 0.2 ? 1.0 : (span - 0.1) / 0.1);
+    return (pad_f + (1.0 - pad_f) * t) * span + 1e-3;
+}
+
 // strict[t] = 1 for the tiles of this row block whose rays may have b in [b_c - lo, b_c + hi]
 void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, double pad_f, std::vector<uint8_t> &strict) {
     const int W = ctx->cfg.width, H = ctx->cfg.height, row0 = ctx->cfg.row0, rows = ctx->rows;
@@ -191,8 +202,9 @@ void classify(const bhr_ctx *ctx, const bhr_camera *cam, double lo, double hi, d
             }
             if (far_cam && outgoing[g] && outgoing[g + 1] && outgoing[g + gx_n] && outgoing[g + gx_n + 1]) continue;
             // b grows with the distance from the hole's image in a convex sense (the field of view stays under 180 degrees): its
-            // maximum over the tile is at a corner, its minimum may lie on an edge -- pad by (a share of) the tile's own span
-            const double pad = pad_f * (double)(bmax - bmin) + 1e-3;
+            // maximum over the tile is at a corner, its minimum may lie on an edge -- pad by the tile's own span; by a share of it
+            // (pad_f) where the span is small against the band (tile_pad)
+            const double pad = tile_pad((double)(bmax - bmin), pad_f);
             if (bmax + pad >= B_CRIT - lo && bmin - pad <= B_CRIT + hi) strict[(size_t)ty * tiles_x + tx] = 1;
         }
 }
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(CLS_EDGE * CLS_EDGE) void hybrid_classify_kernel(Cl
         if (fabs(a.cpn) < PLANE_SIN * (double)blmax && ((ups != 0 && ups != 4) || (double)smin < 1.5 * PLANE_SIN)) f = 1;
         else if (a.far_cam && outs == 4) f = 0;
         else {
-            const double pad = a.pad_f * (double)(bmax - bmin) + 1e-3;
+            const double pad = tile_pad((double)(bmax - bmin), a.pad_f);
             f = (bmax + pad >= B_CRIT - a.lo && bmin - pad <= B_CRIT + a.hi) ? 1 : 0;
         }
         flags[(size_t)ty * a.tiles_x + tx] = (uint8_t)f;

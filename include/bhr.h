@@ -262,7 +262,7 @@ BHR_API int32_t bhr_set_outputs(bhr_ctx *ctx, uint32_t mask);
  *   "bloom_tiles"     BHR_BLOOM_TILES     0 output tiles per wave of the split post-pass by launch size, 1..8 force (A/B runs)
  *   "hybrid_repair"   BHR_HYBRID_REPAIR   -1 guards + strict fix list by view (anti-aliased or tilted), 0 / 1 force
  *   "hybrid_band_lo" / "hybrid_band_hi" / "hybrid_band_default"   BHR_HYBRID_BAND="lo,hi"   strict band around b_c, in r_s
- *   "hybrid_pad"      BHR_HYBRID_PAD      share of a tile's own span of b it is padded by in the strict-band test (default 0.5)
+ *   "hybrid_pad"      BHR_HYBRID_PAD      share of its own span of b a tile spanning <= 0.1 r_s is padded by in the strict-band test (default 0.5; larger tiles: up to all of it)
  *   "hybrid_streams"  BHR_HYBRID_STREAMS  -1 (default) the two lists of a hybrid march on one stream where two frame slots overlap
  *                                         frames and on two where a frame runs alone; 1 / 2 force
  *   "calibrate_streams" BHR_CALIBRATE_STREAMS 1 (default) a context with two frame slots times six candidate streams for slot 1 on
