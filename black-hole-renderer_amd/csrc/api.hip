@@ -792,7 +792,8 @@ int32_t render_on_slot(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags, int 
 // "different queues" (bhr_streams_share_queue finds those): so the context MEASURES.  Once eight two-slot frames have been
 // asked for, six candidate streams (created back to back: they go round HIP's queues) take turns as slot 1's stream for 24
 // frames of the caller's own view, three times; the fastest (by its worst turn) stays, the rest idle.  ~0.2 s, once per context, frames
-// identical to the one asked for; BHR_CALIBRATE_STREAMS=0 / option "calibrate_streams" 0 keeps the first stream.
+// identical to the one asked for; BHR_CALIBRATE_STREAMS=0 / option "calibrate_streams" 0 keeps the first stream, and so does a
+// context whose frames take more than 4 ms (the first turn tells: 4k / 8k frames would spend seconds here for a per cent).
 static int32_t calibrate_slot_streams(bhr_ctx *ctx, const bhr_camera *cam, uint32_t flags) {
     constexpr int NC = 6, FRAMES = 24;
     ctx->calibrating = 1;
@@ -825,7 +826,10 @@ static int32_t calibrate_slot_streams(bhr_ctx *ctx, const bhr_camera *cam, uint3
         for (int i = 0; i < n; ++i) BHR_TRY(bhr_render(ctx, cam, flags));
         return BHR_OK;
     };
-    for (int pass = 0; pass < 3 && rc == BHR_OK; ++pass)
+    // frames of several milliseconds (4k, 8k) gain little from which pair of queues the two slots got and would make this a
+    // matter of seconds: one turn tells, the first stream stays
+    bool long_frames = false;
+    for (int pass = 0; pass < 3 && rc == BHR_OK && !long_frames; ++pass)
         for (int c = 0; c < n_cand && rc == BHR_OK; ++c) {
             rc = drain();
             if (rc != BHR_OK) break;
@@ -837,12 +841,13 @@ static int32_t calibrate_slot_streams(bhr_ctx *ctx, const bhr_camera *cam, uint3
             if (rc == BHR_OK) rc = drain();
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (rc == BHR_OK && (pass == 0 || ms > best_ms[c])) best_ms[c] = ms;      // the WORST of its three turns: a pair has to be good every time
+            if (pass == 0 && c == 0 && ms > 4.0 * FRAMES) { long_frames = true; break; }
         }
     // the level a good pair reaches: the fastest single turn of any candidate
     double good_ms = 1e30;
     for (int c = 0; c < n_cand; ++c) good_ms = best_ms[c] < good_ms ? best_ms[c] : good_ms;
     int best = 0;
-    for (int tries = 0; tries < 4 && rc == BHR_OK; ++tries) {
+    for (int tries = 0; tries < 4 && rc == BHR_OK && !long_frames; ++tries) {
         best = 0;
         // the fastest, with no preference for the earlier ones: a candidate within 1 % of the fastest was, in 8 of 8 bench runs
         // that kept it over the fastest, a pair that later dropped to its slow state (2400 instead of 2900 fps) -- the stream
