@@ -493,6 +493,7 @@ int32_t bhr_create(const bhr_config *cfg, bhr_ctx **out) {
     ctx->split_ok = bhr_split_nt(ctx->bloom_R) <= 12;    // the split-f16 bloom's table: radius <= 176 (widths to 8849)
     ctx->out_want = BHR_OUT_F32;
     if (hipEventCreateWithFlags(&ctx->scene_ev, hipEventDisableTiming) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipEventCreate failed"));
+    if (hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipEventCreate failed"));
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(bhr_fail(BHR_ERR_HIP, "hipEventCreate failed"));
     for (auto &e : ctx->ring_ev)
@@ -553,6 +554,7 @@ void bhr_destroy(bhr_ctx *ctx) {
     if (ctx->d_gather_u8) (void)hipFree(ctx->d_gather_u8);
     free(ctx->h_tile_order);
     if (ctx->scene_ev) (void)hipEventDestroy(ctx->scene_ev);
+    if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
     void *bufs[] = {ctx->d_skybox,
                     ctx->d_wtab, ctx->d_wsum_h, ctx->d_wsum_v, ctx->d_ray_steps, ctx->d_noise_in,
                     ctx->d_noise_out, ctx->d_steps_ring, ctx->d_steps_fold, ctx->d_pool, ctx->d_pairs, ctx->d_stats_scratch, ctx->d_wext, ctx->d_w16, ctx->d_dv2_params,
@@ -568,11 +570,27 @@ void bhr_destroy(bhr_ctx *ctx) {
     delete ctx;
 }
 
+// Waits by POLLING an event for the first 200 ms, then blocks.  hipStreamSynchronize sleeps on an interrupt, and the wake-up is
+// usually 0.1 ms after the GPU is done but every so often 2 ms and more (bench line of a 20-step run: the 20 frames' own event
+// span 6.6 ms in both of two runs, the host back after 6.7 and after 8.7 ms -- a quarter of the frame rate of a run that short;
+// profiles/r04e_sync_wakeup.txt).  A frame loop that waits once per batch can afford a core for its wait.
+static int32_t poll_sync(bhr_ctx *ctx, hipStream_t stream) {
+    BHR_HIP(hipEventRecord(ctx->sync_ev, stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ctx->sync_ev);
+        if (e == hipSuccess) return BHR_OK;
+        if (e != hipErrorNotReady) BHR_HIP(e);
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+    }
+    BHR_HIP(hipStreamSynchronize(stream));
+    return BHR_OK;
+}
+
 int32_t bhr_sync(bhr_ctx *ctx) {
     if (!ctx) return bhr_fail(BHR_ERR_INVALID, "null ctx");
     BHR_TRY(use_device(ctx));
-    BHR_HIP(hipStreamSynchronize(ctx->stream));
-    return BHR_OK;
+    return poll_sync(ctx, ctx->stream);
 }
 
 int32_t bhr_set_skybox(bhr_ctx *ctx, const float *rgb, int32_t tex_h, int32_t tex_w) {
@@ -814,10 +832,10 @@ static int32_t calibrate_slot_streams(bhr_ctx *ctx, const bhr_camera *cam, uint3
     // on record in (with the ring left to run, three turns of six candidates are 628 frames of a ring of 512).  The next
     // frames' counter cells are cleared as the V pass of their predecessors would have left them.
     auto drain = [&]() -> int32_t {
-        for (int k = 0; k < 2; ++k) BHR_HIP(hipStreamSynchronize(ctx->slots[k].stream));
+        for (int k = 0; k < 2; ++k) BHR_TRY(poll_sync(ctx, ctx->slots[k].stream));      // (polled: a turn is 8 ms, an interrupt's wake-up up to 2)
         for (int q = 0; q < BHR_MAX_FRAME_SLOTS; ++q)
             BHR_HIP(hipMemsetAsync(ctx->d_steps_ring + (size_t)((head0 + q) % BHR_TIMING_RING) * BHR_STEP_CELL, 0, sizeof(unsigned long long) * BHR_STEP_CELL, ctx->scene_stream));
-        BHR_HIP(hipStreamSynchronize(ctx->scene_stream));
+        BHR_TRY(poll_sync(ctx, ctx->scene_stream));
         ctx->ring_head = head0;
         ctx->next_slot = slot0;
         return BHR_OK;

@@ -192,6 +192,7 @@ struct bhr_ctx {
     int32_t n_calib_idle;
     hipEvent_t scene_ev;                // scene stream -> slot stream ordering, recorded at every bhr_render
     hipEvent_t ev[8];
+    hipEvent_t sync_ev;                 // bhr_sync polls it (no timing)
     // per-frame timing ring: 3 events per bhr_render (march start, march end, frame end)
     hipEvent_t ring_ev[BHR_TIMING_RING * 3];
     unsigned long long *d_steps_ring;   // one ray-step counter cell (BHR_STEP_CELL words) per ring slot
